@@ -1,0 +1,1283 @@
+/*
+ * gym_oracle.c -- CPU restatement of the reference's batched-step path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see gym_oracle.h for the parity status).
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math -std=c11 (oracle/Makefile).
+ * -ffp-contract=off matters: CoreCLR on x64 evaluates `float op float` with
+ * scalar SSE and rounds to binary32 after every operation and never fuses
+ * a*b+c, so this file must not either.  Math.Sin/Cos/Atan2 are double->double
+ * calls into the platform libm on Linux, which is the glibc linked here.
+ *
+ * Typing rules followed throughout (C# 12 / net8.0):
+ *   float op float   -> float (one rounding per op)
+ *   int   op float   -> float
+ *   x op double      -> double          (double literals, Math.PI)
+ *   (float)expr      -> one rounding of the double value
+ *   const float expressions are folded in binary32, operation by operation.
+ * The C compiler applies the same rules to the same expressions, so the
+ * source below keeps the reference's expression shapes instead of pre-folded
+ * literals.
+ */
+#define _GNU_SOURCE
+#include "gym_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+/* ======================================================================
+ * Counter-based RNG (build-defined).
+ *
+ * The reference owns an unseeded `new Random()` per env and per space
+ * (Envs.CartPole.cs:19, Spaces.Box.cs:14, Spaces.Discrete.cs:11) and
+ * Env.Seed is an empty virtual (Env.cs:33-36), so its draws cannot be
+ * reproduced.  The build defines instead
+ *     x   = Philox4x32-10(key = seed, ctr = (env_lo, env_hi, tick_lo,
+ *                         stream<<24 | tick_hi8<<16 | block))
+ *     u64 = words (1:0) for even draws, (3:2) for odd draws, block = draw/2
+ *     u   = (u64 >> 11) * 2^-53  in [0,1)
+ * with `tick` = number of Reset()/Step() calls made on the batch before the
+ * one that consumes the draw.  Streams: 0 = Reset draws, 1 = draws an env
+ * makes inside Step, 2 = action-space samples of the random policy.
+ * ====================================================================== */
+void gxo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+  uint32_t k0 = key[0], k1 = key[1];
+  for (int r = 0; r < 10; r++) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+uint64_t gxo_rng_u64(uint64_t seed, uint64_t env_index, uint64_t tick, uint32_t stream, uint32_t draw) {
+  uint32_t ctr[4], key[2], out[4];
+  ctr[0] = (uint32_t)env_index;
+  ctr[1] = (uint32_t)(env_index >> 32);
+  ctr[2] = (uint32_t)tick;
+  ctr[3] = (stream << 24) | ((uint32_t)((tick >> 32) & 0xFFu) << 16) | ((draw >> 1) & 0xFFFFu);
+  key[0] = (uint32_t)seed;
+  key[1] = (uint32_t)(seed >> 32);
+  gxo_philox4x32_10(ctr, key, out);
+  return (draw & 1u) ? (((uint64_t)out[3] << 32) | out[2]) : (((uint64_t)out[1] << 32) | out[0]);
+}
+
+double gxo_rng_uniform(uint64_t seed, uint64_t env_index, uint64_t tick, uint32_t stream, uint32_t draw) {
+  return (double)(gxo_rng_u64(seed, env_index, tick, stream, draw) >> 11) * 0x1.0p-53;
+}
+
+/* Random.Next(n) stand-in (Spaces.Discrete.cs:18, Envs.Taxi.cs:20): the high
+ * 32 bits of the draw scaled into [0,n) by multiply-shift. */
+int32_t gxo_rng_below(uint64_t seed, uint64_t env_index, uint64_t tick, uint32_t stream, uint32_t draw, int32_t n) {
+  uint64_t hi = gxo_rng_u64(seed, env_index, tick, stream, draw) >> 32;
+  return (int32_t)((hi * (uint64_t)(uint32_t)n) >> 32);
+}
+
+/* Spaces.Box.cs:30 -- `(float)(NextDouble() * (High[i] - Low[i]) + Low[i])`:
+ * the range is a binary32 subtraction, promoted to double for the rest. */
+float gxo_box_sample(double u, float low, float high) {
+  float range = high - low;
+  return (float)(u * (double)range + (double)low);
+}
+
+/* ======================================================================
+ * Per-env objects with a virtual Reset/Step, like Env<TState,TAction>
+ * (Env.cs:7-52).  The RNG context replaces the private `_rng` field.
+ * ====================================================================== */
+typedef struct rng_ctx {
+  uint64_t seed;
+  uint64_t env_index;
+  uint64_t tick;
+} rng_ctx;
+
+typedef struct env_obj env_obj;
+typedef struct env_vtbl {
+  void (*reset)(env_obj*, const rng_ctx*);
+  /* returns 0, or -1 where the reference throws */
+  int (*step)(env_obj*, const void* action, const rng_ctx*, double* reward, int* done);
+  void (*export_state)(const env_obj*, void* reals, int32_t* ints);
+  void (*import_state)(env_obj*, const void* reals, const int32_t* ints);
+  size_t size;
+} env_vtbl;
+struct env_obj {
+  const env_vtbl* vt;
+};
+
+static inline float clampf(float v, float lo, float hi) {
+  /* Math.Clamp(float,float,float): value<min -> min, value>max -> max */
+  if (v < lo) return lo;
+  if (v > hi) return hi;
+  return v;
+}
+
+/* ---------------------------------------------------------------- CartPole */
+typedef struct {
+  env_obj base;
+  float s[4];
+  int32_t steps;
+} cartpole_t;
+
+/* Envs.CartPole.cs:22-32 */
+static void cartpole_reset(env_obj* e, const rng_ctx* r) {
+  cartpole_t* c = (cartpole_t*)e;
+  for (uint32_t i = 0; i < 4; i++)
+    c->s[i] = (float)(gxo_rng_uniform(r->seed, r->env_index, r->tick, 0, i) * 0.1 - 0.05);
+  c->steps = 0;
+}
+
+/* Envs.CartPole.cs:34-75 */
+static int cartpole_step(env_obj* e, const void* action, const rng_ctx* r, double* reward, int* done) {
+  (void)r;
+  cartpole_t* c = (cartpole_t*)e;
+  int a = *(const int32_t*)action;
+  const float gravity = 9.8f;
+  const float masscart = 1.0f;
+  const float masspole = 0.1f;
+  const float total_mass = masscart + masspole;
+  const float length = 0.5f;
+  const float polemass_length = masspole * length;
+  const float force_mag = 10.0f;
+  const float tau = 0.02f;
+  const float theta_threshold_radians = 12 * (float)M_PI / 180;
+  const float x_threshold = 2.4f;
+
+  float x = c->s[0], xDot = c->s[1], theta = c->s[2], thetaDot = c->s[3];
+  float force = a == 1 ? force_mag : -force_mag;
+  float costheta = (float)cos((double)theta);
+  float sintheta = (float)sin((double)theta);
+
+  float temp = (force + polemass_length * thetaDot * thetaDot * sintheta) / total_mass;
+  float thetaacc = (gravity * sintheta - costheta * temp) /
+                   (length * (4.0f / 3.0f - masspole * costheta * costheta / total_mass));
+  float xacc = temp - polemass_length * thetaacc * costheta / total_mass;
+
+  x += tau * xDot;
+  xDot += tau * xacc;
+  theta += tau * thetaDot;
+  thetaDot += tau * thetaacc;
+  c->s[0] = x; c->s[1] = xDot; c->s[2] = theta; c->s[3] = thetaDot;
+  c->steps++;
+
+  int d = x < -x_threshold || x > x_threshold || theta < -theta_threshold_radians ||
+          theta > theta_threshold_radians || c->steps >= 500;
+  *done = d;
+  *reward = !d ? 1.0 : 0.0;
+  return 0;
+}
+
+static void f32x_export(const float* s, int n, int32_t steps, void* reals, int32_t* ints) {
+  memcpy(reals, s, sizeof(float) * (size_t)n);
+  ints[0] = steps;
+}
+
+static void cartpole_export(const env_obj* e, void* reals, int32_t* ints) {
+  const cartpole_t* c = (const cartpole_t*)e;
+  f32x_export(c->s, 4, c->steps, reals, ints);
+}
+static void cartpole_import(env_obj* e, const void* reals, const int32_t* ints) {
+  cartpole_t* c = (cartpole_t*)e;
+  memcpy(c->s, reals, sizeof c->s);
+  c->steps = ints[0];
+}
+static const env_vtbl cartpole_vt = {cartpole_reset, cartpole_step, cartpole_export, cartpole_import, sizeof(cartpole_t)};
+
+/* ------------------------------------------------------------- MountainCar */
+typedef struct {
+  env_obj base;
+  float s[2];
+  int32_t steps;
+} mcar_t;
+
+/* Envs.MountainCar.cs:22-30, Envs.MountainCarContinuous.cs:19-27 */
+static void mcar_reset(env_obj* e, const rng_ctx* r) {
+  mcar_t* c = (mcar_t*)e;
+  c->s[0] = (float)(gxo_rng_uniform(r->seed, r->env_index, r->tick, 0, 0) * 0.2 - 0.6);
+  c->s[1] = 0.0f;
+  c->steps = 0;
+}
+
+/* Envs.MountainCar.cs:32-50 */
+static int mcar_step(env_obj* e, const void* action, const rng_ctx* r, double* reward, int* done) {
+  (void)r;
+  mcar_t* c = (mcar_t*)e;
+  int a = *(const int32_t*)action;
+  float position = c->s[0], velocity = c->s[1];
+  float force = (float)(a - 1);
+  velocity += 0.001f * force - 0.0025f * (float)cos((double)(3 * position));
+  velocity = clampf(velocity, -0.07f, 0.07f);
+  position += velocity;
+  if (position < -1.2f) {
+    position = -1.2f;
+    velocity = 0.0f;
+  }
+  int d = position >= 0.5f;
+  *done = d;
+  *reward = d ? 0.0 : -1.0;
+  c->s[0] = position; c->s[1] = velocity;
+  c->steps++;
+  return 0;
+}
+
+/* Envs.MountainCarContinuous.cs:29-49 */
+static int mcc_step(env_obj* e, const void* action, const rng_ctx* r, double* reward, int* done) {
+  (void)r;
+  mcar_t* c = (mcar_t*)e;
+  float act = *(const float*)action;
+  float position = c->s[0], velocity = c->s[1];
+  float force = clampf(act, -1.0f, 1.0f);
+  velocity += force * 0.0015f - 0.0025f * (float)cos((double)(3 * position));
+  velocity = clampf(velocity, -0.07f, 0.07f);
+  position += velocity;
+  if (position < -1.2f) {
+    position = -1.2f;
+    velocity = 0.0f;
+  }
+  int d = position >= 0.45f;
+  double rew = (double)velocity * 0.1;
+  if (d && position >= 0.45f) rew += 100.0;
+  *done = d;
+  *reward = rew;
+  c->s[0] = position; c->s[1] = velocity;
+  c->steps++;
+  return 0;
+}
+
+static void mcar_export(const env_obj* e, void* reals, int32_t* ints) {
+  const mcar_t* c = (const mcar_t*)e;
+  f32x_export(c->s, 2, c->steps, reals, ints);
+}
+static void mcar_import(env_obj* e, const void* reals, const int32_t* ints) {
+  mcar_t* c = (mcar_t*)e;
+  memcpy(c->s, reals, sizeof c->s);
+  c->steps = ints[0];
+}
+static const env_vtbl mcar_vt = {mcar_reset, mcar_step, mcar_export, mcar_import, sizeof(mcar_t)};
+static const env_vtbl mcc_vt = {mcar_reset, mcc_step, mcar_export, mcar_import, sizeof(mcar_t)};
+
+/* ---------------------------------------------------------------- Pendulum */
+typedef struct {
+  env_obj base;
+  float s[3];
+  int32_t steps;
+} pendulum_t;
+
+/* Envs.Pendulum.cs:19-28 */
+static void pendulum_reset(env_obj* e, const rng_ctx* r) {
+  pendulum_t* c = (pendulum_t*)e;
+  float theta = (float)(gxo_rng_uniform(r->seed, r->env_index, r->tick, 0, 0) * 2 * M_PI - M_PI);
+  float thetaDot = (float)(gxo_rng_uniform(r->seed, r->env_index, r->tick, 0, 1) * 1 - 0.5);
+  c->s[0] = (float)cos((double)theta);
+  c->s[1] = (float)sin((double)theta);
+  c->s[2] = thetaDot;
+  c->steps = 0;
+}
+
+/* Envs.Pendulum.cs:30-60 */
+static int pendulum_step(env_obj* e, const void* action, const rng_ctx* r, double* reward, int* done) {
+  (void)r;
+  pendulum_t* c = (pendulum_t*)e;
+  float act = *(const float*)action;
+  const float max_speed = 8.0f;
+  const float max_torque = 2.0f;
+  const float dt = 0.05f;
+  const float g = 10.0f;
+  const float m = 1.0f;
+  const float l = 1.0f;
+
+  float theta = (float)atan2((double)c->s[1], (double)c->s[0]);
+  float thetaDot = c->s[2];
+  float u = clampf(act, -max_torque, max_torque);
+
+  float new_thetaDot =
+      thetaDot + (-3 * g / (2 * l) * (float)sin((double)theta + M_PI) + 3.0f / (m * l * l) * u) * dt;
+  new_thetaDot = clampf(new_thetaDot, -max_speed, max_speed);
+  float new_theta = theta + new_thetaDot * dt;
+
+  c->s[0] = (float)cos((double)new_theta);
+  c->s[1] = (float)sin((double)new_theta);
+  c->s[2] = new_thetaDot;
+  c->steps++;
+
+  /* `theta * theta` is float*float (binary32 product) promoted to double;
+   * `0.1 * thetaDot * thetaDot` is ((0.1*thetaDot)*thetaDot) in double. */
+  *reward = -((double)(theta * theta) + 0.1 * (double)thetaDot * (double)thetaDot +
+              0.001 * (double)u * (double)u);
+  *done = 0;
+  return 0;
+}
+
+static void pendulum_export(const env_obj* e, void* reals, int32_t* ints) {
+  const pendulum_t* c = (const pendulum_t*)e;
+  f32x_export(c->s, 3, c->steps, reals, ints);
+}
+static void pendulum_import(env_obj* e, const void* reals, const int32_t* ints) {
+  pendulum_t* c = (pendulum_t*)e;
+  memcpy(c->s, reals, sizeof c->s);
+  c->steps = ints[0];
+}
+static const env_vtbl pendulum_vt = {pendulum_reset, pendulum_step, pendulum_export, pendulum_import, sizeof(pendulum_t)};
+
+/* ----------------------------------------------------------------- Acrobot */
+typedef struct {
+  env_obj base;
+  float s[6];
+  int32_t steps;
+} acrobot_t;
+
+/* Envs.Acrobot.cs:22-28 -- all six slots get a small uniform draw. */
+static void acrobot_reset(env_obj* e, const rng_ctx* r) {
+  acrobot_t* c = (acrobot_t*)e;
+  for (uint32_t i = 0; i < 6; i++)
+    c->s[i] = (float)(gxo_rng_uniform(r->seed, r->env_index, r->tick, 0, i) * 0.1 - 0.05);
+  c->steps = 0;
+}
+
+/* Envs.Acrobot.cs:30-91 -- semi-implicit Euler in binary32, no angle wrap. */
+static int acrobot_step(env_obj* e, const void* action, const rng_ctx* r, double* reward, int* done) {
+  (void)r;
+  acrobot_t* c = (acrobot_t*)e;
+  int a = *(const int32_t*)action;
+  const float LINK_LENGTH_1 = 1.0f;
+  const float LINK_LENGTH_2 = 1.0f;
+  const float LINK_MASS_1 = 1.0f;
+  const float LINK_MASS_2 = 1.0f;
+  const float LINK_COM_POS_1 = 0.5f;
+  const float LINK_COM_POS_2 = 0.5f;
+  const float LINK_MOI_1 = 1.0f;
+  const float LINK_MOI_2 = 1.0f;
+  const float MAX_VEL_1 = 4 * (float)M_PI;
+  const float MAX_VEL_2 = 9 * (float)M_PI;
+  const float dt = 0.2f;
+  const float g = 9.8f;
+  const float torque[3] = {-1.0f, 0.0f, 1.0f};
+  if (a < 0 || a > 2) return -1; /* IndexOutOfRangeException, Envs.Acrobot.cs:51 */
+
+  float theta1 = (float)atan2((double)c->s[1], (double)c->s[0]);
+  float theta2 = (float)atan2((double)c->s[3], (double)c->s[2]);
+  float dtheta1 = c->s[4];
+  float dtheta2 = c->s[5];
+  float u = torque[a];
+
+  float d1 = LINK_MASS_1 * LINK_COM_POS_1 * LINK_COM_POS_1 +
+             LINK_MASS_2 * (LINK_LENGTH_1 * LINK_LENGTH_1 + LINK_COM_POS_2 * LINK_COM_POS_2 +
+                            2 * LINK_LENGTH_1 * LINK_COM_POS_2 * (float)cos((double)theta2)) +
+             LINK_MOI_1 + LINK_MOI_2;
+  float d2 = LINK_MASS_2 * (LINK_COM_POS_2 * LINK_COM_POS_2 +
+                            LINK_LENGTH_1 * LINK_COM_POS_2 * (float)cos((double)theta2)) +
+             LINK_MOI_2;
+  float phi2 = LINK_MASS_2 * LINK_COM_POS_2 * g * (float)cos((double)(theta1 + theta2) - M_PI / 2.0);
+  float phi1 = -LINK_MASS_2 * LINK_LENGTH_1 * LINK_COM_POS_2 * dtheta2 * dtheta2 * (float)sin((double)theta2) -
+               2 * LINK_MASS_2 * LINK_LENGTH_1 * LINK_COM_POS_2 * dtheta2 * dtheta1 * (float)sin((double)theta2) +
+               (LINK_MASS_1 * LINK_COM_POS_1 + LINK_MASS_2 * LINK_LENGTH_1) * g *
+                   (float)cos((double)theta1 - M_PI / 2.0) +
+               phi2;
+  float ddtheta2 = (u + d2 / d1 * phi1 -
+                    LINK_MASS_2 * LINK_LENGTH_1 * LINK_COM_POS_2 * dtheta1 * dtheta1 * (float)sin((double)theta2) - phi2) /
+                   (LINK_MASS_2 * LINK_COM_POS_2 * LINK_COM_POS_2 + LINK_MOI_2 - d2 * d2 / d1);
+  float ddtheta1 = -(d2 * ddtheta2 + phi1) / d1;
+
+  dtheta1 += dt * ddtheta1;
+  dtheta2 += dt * ddtheta2;
+  dtheta1 = clampf(dtheta1, -MAX_VEL_1, MAX_VEL_1);
+  dtheta2 = clampf(dtheta2, -MAX_VEL_2, MAX_VEL_2);
+  theta1 += dt * dtheta1;
+  theta2 += dt * dtheta2;
+
+  c->s[0] = (float)cos((double)theta1);
+  c->s[1] = (float)sin((double)theta1);
+  c->s[2] = (float)cos((double)theta2);
+  c->s[3] = (float)sin((double)theta2);
+  c->s[4] = dtheta1;
+  c->s[5] = dtheta2;
+  c->steps++;
+
+  float tip_y = -LINK_LENGTH_1 * (float)cos((double)theta1) - LINK_LENGTH_2 * (float)cos((double)(theta1 + theta2));
+  int d = tip_y > 1.0f || c->steps >= 500;
+  *done = d;
+  *reward = d ? 0.0 : -1.0;
+  return 0;
+}
+
+static void acrobot_export(const env_obj* e, void* reals, int32_t* ints) {
+  const acrobot_t* c = (const acrobot_t*)e;
+  f32x_export(c->s, 6, c->steps, reals, ints);
+}
+static void acrobot_import(env_obj* e, const void* reals, const int32_t* ints) {
+  acrobot_t* c = (acrobot_t*)e;
+  memcpy(c->s, reals, sizeof c->s);
+  c->steps = ints[0];
+}
+static const env_vtbl acrobot_vt = {acrobot_reset, acrobot_step, acrobot_export, acrobot_import, sizeof(acrobot_t)};
+
+/* ------------------------------------------- Acrobot, upstream RK4 in fp64
+ * EXTENSION (parity unpinned by the reference, which integrates with
+ * semi-implicit Euler in binary32, Envs.Acrobot.cs:69-74).  Follows the
+ * published Gymnasium "book" dynamics with the same constants: state
+ * (theta1, theta2, dtheta1, dtheta2) in double, one classical RK4 step of
+ * dt = 0.2, wrap of both angles to [-pi, pi), velocity bounds 4pi / 9pi,
+ * terminal when -cos(t1) - cos(t1 + t2) > 1 or steps >= 500.  Reset draws
+ * four uniforms in [-0.1, 0.1).  Every a*b+c below is written with fma() so
+ * that a device build, which contracts, can match bit-for-bit wherever the
+ * transcendental results agree. */
+typedef struct {
+  env_obj base;
+  double s[4];
+  int32_t steps;
+} acrobot64_t;
+
+static void acrobot64_reset(env_obj* e, const rng_ctx* r) {
+  acrobot64_t* c = (acrobot64_t*)e;
+  for (uint32_t i = 0; i < 4; i++)
+    c->s[i] = fma(gxo_rng_uniform(r->seed, r->env_index, r->tick, 0, i), 0.2, -0.1);
+  c->steps = 0;
+}
+
+static inline void acrobot64_dsdt(const double y[4], double u, double dy[4]) {
+  const double g = 9.8;
+  double t1 = y[0], t2 = y[1], w1 = y[2], w2 = y[3];
+  double c2 = cos(t2), s2 = sin(t2);
+  /* m1*lc1^2 + m2*(l1^2 + lc2^2 + 2*l1*lc2*cos t2) + I1 + I2 with unit masses
+   * and lengths, lc = 0.5, I = 1 */
+  double d1 = c2 + 3.5;
+  double d2 = fma(0.5, c2, 1.25);
+  double phi2 = (0.5 * g) * cos(t1 + t2 - M_PI / 2.0);
+  double phi1 = fma(1.5 * g, cos(t1 - M_PI / 2.0), phi2);
+  phi1 = fma(-(w2 * s2), w1, phi1);
+  phi1 = fma(-0.5 * (w2 * s2), w2, phi1);
+  double r = d2 / d1;
+  double num = fma(r, phi1, u);
+  num = fma(-0.5 * (w1 * s2), w1, num) - phi2;
+  double den = fma(-d2, r, 1.25);
+  double a2 = num / den;
+  double a1 = -fma(d2, a2, phi1) / d1;
+  dy[0] = w1; dy[1] = w2; dy[2] = a1; dy[3] = a2;
+}
+
+static inline double wrap_pi(double x) {
+  /* upstream wrap(x, -pi, pi): repeated +-2pi until inside [-pi, pi] */
+  const double two_pi = 2.0 * M_PI;
+  while (x > M_PI) x -= two_pi;
+  while (x < -M_PI) x += two_pi;
+  return x;
+}
+
+static int acrobot64_step(env_obj* e, const void* action, const rng_ctx* r, double* reward, int* done) {
+  (void)r;
+  acrobot64_t* c = (acrobot64_t*)e;
+  int a = *(const int32_t*)action;
+  if (a < 0 || a > 2) return -1;
+  const double dt = 0.2;
+  double u = (double)(a - 1);
+  double y0[4] = {c->s[0], c->s[1], c->s[2], c->s[3]};
+  double k1[4], k2[4], k3[4], k4[4], y[4];
+  acrobot64_dsdt(y0, u, k1);
+  for (int i = 0; i < 4; i++) y[i] = fma(0.5 * dt, k1[i], y0[i]);
+  acrobot64_dsdt(y, u, k2);
+  for (int i = 0; i < 4; i++) y[i] = fma(0.5 * dt, k2[i], y0[i]);
+  acrobot64_dsdt(y, u, k3);
+  for (int i = 0; i < 4; i++) y[i] = fma(dt, k3[i], y0[i]);
+  acrobot64_dsdt(y, u, k4);
+  for (int i = 0; i < 4; i++) {
+    double sum = fma(2.0, k2[i], k1[i]);
+    sum = fma(2.0, k3[i], sum) + k4[i];
+    y[i] = fma(dt / 6.0, sum, y0[i]);
+  }
+  y[0] = wrap_pi(y[0]);
+  y[1] = wrap_pi(y[1]);
+  const double mv1 = 4.0 * M_PI, mv2 = 9.0 * M_PI;
+  y[2] = y[2] < -mv1 ? -mv1 : (y[2] > mv1 ? mv1 : y[2]);
+  y[3] = y[3] < -mv2 ? -mv2 : (y[3] > mv2 ? mv2 : y[3]);
+  for (int i = 0; i < 4; i++) c->s[i] = y[i];
+  c->steps++;
+  int d = (-cos(y[0]) - cos(y[1] + y[0]) > 1.0) || c->steps >= 500;
+  *done = d;
+  *reward = d ? 0.0 : -1.0;
+  return 0;
+}
+
+static void acrobot64_export(const env_obj* e, void* reals, int32_t* ints) {
+  const acrobot64_t* c = (const acrobot64_t*)e;
+  memcpy(reals, c->s, sizeof c->s);
+  ints[0] = c->steps;
+}
+static void acrobot64_import(env_obj* e, const void* reals, const int32_t* ints) {
+  acrobot64_t* c = (acrobot64_t*)e;
+  memcpy(c->s, reals, sizeof c->s);
+  c->steps = ints[0];
+}
+static const env_vtbl acrobot64_vt = {acrobot64_reset, acrobot64_step, acrobot64_export, acrobot64_import, sizeof(acrobot64_t)};
+
+/* ---------------------------------------------------- grid worlds (tabular) */
+#define GRID_MAX_CELLS 4096
+typedef struct grid_desc {
+  int nrow, ncol, start, goal;
+  int step_limit;
+  uint8_t hole[GRID_MAX_CELLS]; /* FrozenLake holes / CliffWalking cliff */
+  int is_cliff;
+  int slippery;
+} grid_desc;
+
+typedef struct {
+  env_obj base;
+  const grid_desc* g;
+  int32_t state;
+  int32_t steps;
+} grid_t;
+
+/* Envs.FrozenLake.cs:45-50, Envs.CliffWalking.cs:29-34 */
+static void grid_reset(env_obj* e, const rng_ctx* r) {
+  (void)r;
+  grid_t* c = (grid_t*)e;
+  c->state = c->g->start;
+  c->steps = 0;
+}
+
+/* Envs.FrozenLake.cs:52-69, Envs.CliffWalking.cs:36-54 */
+static int grid_step(env_obj* e, const void* action, const rng_ctx* r, double* reward, int* done) {
+  grid_t* c = (grid_t*)e;
+  const grid_desc* g = c->g;
+  int a = *(const int32_t*)action;
+  if (g->slippery && a >= 0 && a <= 3) {
+    /* EXTENSION (upstream is_slippery; the reference declares _rng and never
+     * uses it, Envs.FrozenLake.cs:16): the executed action is a-1, a or a+1
+     * (mod 4) with probability 1/3 each. */
+    int k = gxo_rng_below(r->seed, r->env_index, r->tick, 1, 0, 3);
+    a = (a + 3 + k) & 3;
+  }
+  int row = c->state / g->ncol;
+  int col = c->state % g->ncol;
+  switch (a) {
+    case 0: col = col - 1 > 0 ? col - 1 : 0; break;
+    case 1: row = row + 1 < g->nrow - 1 ? row + 1 : g->nrow - 1; break;
+    case 2: col = col + 1 < g->ncol - 1 ? col + 1 : g->ncol - 1; break;
+    case 3: row = row - 1 > 0 ? row - 1 : 0; break;
+    default: break;
+  }
+  c->state = row * g->ncol + col;
+  c->steps++;
+  int at_goal = c->state == g->goal;
+  int in_hole = g->hole[c->state];
+  *done = at_goal || in_hole || c->steps >= g->step_limit;
+  if (g->is_cliff) {
+    double rew = in_hole ? -100.0 : -1.0;
+    if (at_goal) rew = 0.0;
+    *reward = rew;
+  } else {
+    *reward = at_goal ? 1.0 : 0.0;
+  }
+  return 0;
+}
+
+static void grid_export(const env_obj* e, void* reals, int32_t* ints) {
+  (void)reals;
+  const grid_t* c = (const grid_t*)e;
+  ints[0] = c->state;
+  ints[1] = c->steps;
+}
+static void grid_import(env_obj* e, const void* reals, const int32_t* ints) {
+  (void)reals;
+  grid_t* c = (grid_t*)e;
+  c->state = ints[0];
+  c->steps = ints[1];
+}
+static const env_vtbl grid_vt = {grid_reset, grid_step, grid_export, grid_import, sizeof(grid_t)};
+
+/* -------------------------------------------------------------------- Taxi */
+typedef struct {
+  env_obj base;
+  int32_t state;
+  int32_t steps;
+  int full;
+} taxi_t;
+
+/* Envs.Taxi.cs:18-23 */
+static void taxi_reset(env_obj* e, const rng_ctx* r) {
+  taxi_t* c = (taxi_t*)e;
+  if (!c->full) {
+    c->state = gxo_rng_below(r->seed, r->env_index, r->tick, 0, 0, 500);
+  } else {
+    /* EXTENSION: upstream draws only states whose passenger is not already
+     * at the destination and not in the taxi: 25 cells * 4 pass * 3 dest. */
+    int k = gxo_rng_below(r->seed, r->env_index, r->tick, 0, 0, 300);
+    int cell = k / 12, rem = k % 12, pass = rem / 3, d3 = rem % 3;
+    int dest = d3 >= pass ? d3 + 1 : d3;
+    c->state = (cell * 5 + pass) * 4 + dest;
+  }
+  c->steps = 0;
+}
+
+/* EXTENSION: upstream Taxi-v3 transition (5x5 grid, walls, 4 depots). */
+static void taxi_full_transition(int s, int a, int* ns, double* rew, int* term) {
+  static const int loc_r[4] = {0, 0, 4, 4};
+  static const int loc_c[4] = {0, 4, 0, 3};
+  /* wall_e[r][c] = 1 when a wall blocks moving east out of (r,c) */
+  static const uint8_t wall_e[5][5] = {
+      {0, 1, 0, 0, 1}, {0, 1, 0, 0, 1}, {0, 0, 0, 0, 1}, {1, 0, 1, 0, 1}, {1, 0, 1, 0, 1}};
+  int dest = s % 4, pass = (s / 4) % 5, col = (s / 20) % 5, row = s / 100;
+  double r = -1.0;
+  int t = 0;
+  switch (a) {
+    case 0: row = row + 1 < 4 ? row + 1 : 4; break;          /* south */
+    case 1: row = row - 1 > 0 ? row - 1 : 0; break;          /* north */
+    case 2: if (!wall_e[row][col]) col = col + 1; break;     /* east */
+    case 3: if (col > 0 && !wall_e[row][col - 1]) col = col - 1; break; /* west */
+    case 4: /* pickup */
+      if (pass < 4 && row == loc_r[pass] && col == loc_c[pass]) pass = 4;
+      else r = -10.0;
+      break;
+    case 5: /* dropoff */
+      if (pass == 4 && row == loc_r[dest] && col == loc_c[dest]) {
+        pass = dest; r = 20.0; t = 1;
+      } else if (pass == 4 && ((row == 0 && col == 0) || (row == 0 && col == 4) ||
+                               (row == 4 && col == 0) || (row == 4 && col == 3))) {
+        for (int k = 0; k < 4; k++)
+          if (row == loc_r[k] && col == loc_c[k]) pass = k;
+      } else {
+        r = -10.0;
+      }
+      break;
+    default: break;
+  }
+  *ns = ((row * 5 + col) * 5 + pass) * 4 + dest;
+  *rew = r;
+  *term = t;
+}
+
+/* Envs.Taxi.cs:25-33 -- the reference is a stub: the state never changes. */
+static int taxi_step(env_obj* e, const void* action, const rng_ctx* r, double* reward, int* done) {
+  (void)r;
+  taxi_t* c = (taxi_t*)e;
+  int a = *(const int32_t*)action;
+  c->steps++;
+  if (!c->full) {
+    *done = c->steps >= 200;
+    *reward = -1.0;
+  } else {
+    int ns, t;
+    double rew;
+    taxi_full_transition(c->state, a, &ns, &rew, &t);
+    c->state = ns;
+    *done = t || c->steps >= 200;
+    *reward = rew;
+  }
+  return 0;
+}
+
+static void taxi_export(const env_obj* e, void* reals, int32_t* ints) {
+  (void)reals;
+  const taxi_t* c = (const taxi_t*)e;
+  ints[0] = c->state;
+  ints[1] = c->steps;
+}
+static void taxi_import(env_obj* e, const void* reals, const int32_t* ints) {
+  (void)reals;
+  taxi_t* c = (taxi_t*)e;
+  c->state = ints[0];
+  c->steps = ints[1];
+}
+static const env_vtbl taxi_vt = {taxi_reset, taxi_step, taxi_export, taxi_import, sizeof(taxi_t)};
+
+/* ------------------------------------------------------------------- Dummy */
+typedef struct {
+  env_obj base;
+  int32_t state;
+  int32_t steps;
+} dummy_t;
+
+/* DummyEnv.cs:17-21 */
+static void dummy_reset(env_obj* e, const rng_ctx* r) {
+  (void)r;
+  dummy_t* c = (dummy_t*)e;
+  c->state = 0;
+  c->steps = 0;
+}
+/* DummyEnv.cs:23-30 */
+static int dummy_step(env_obj* e, const void* action, const rng_ctx* r, double* reward, int* done) {
+  (void)r;
+  dummy_t* c = (dummy_t*)e;
+  c->state += *(const int32_t*)action;
+  c->steps++;
+  *reward = (double)c->state;
+  *done = c->state >= 10;
+  return 0;
+}
+static void dummy_export(const env_obj* e, void* reals, int32_t* ints) {
+  (void)reals;
+  const dummy_t* c = (const dummy_t*)e;
+  ints[0] = c->state;
+  ints[1] = c->steps;
+}
+static void dummy_import(env_obj* e, const void* reals, const int32_t* ints) {
+  (void)reals;
+  dummy_t* c = (dummy_t*)e;
+  c->state = ints[0];
+  c->steps = ints[1];
+}
+static const env_vtbl dummy_vt = {dummy_reset, dummy_step, dummy_export, dummy_import, sizeof(dummy_t)};
+
+/* -------------------------------------------------------------------- Pong */
+#define SCREEN_WIDTH 160
+#define SCREEN_HEIGHT 210
+#define CHANNELS 3
+#define PADDLE_SPEED 4.0
+#define BALL_SPEED 3.0
+#define PADDLE_HEIGHT 15
+#define PADDLE_WIDTH 2
+#define BALL_SIZE 2
+
+typedef struct {
+  env_obj base;
+  double ballX, ballY, ballVelX, ballVelY, leftPaddleY, rightPaddleY;
+  int32_t leftScore, rightScore, steps;
+} pong_t;
+
+/* Envs.Pong.cs:159-165; `reset_stream` = 0 from Reset, 1 from inside Step */
+static void pong_reset_ball(pong_t* c, const rng_ctx* r, uint32_t stream) {
+  c->ballX = SCREEN_WIDTH / 2.0;
+  c->ballY = SCREEN_HEIGHT / 2.0;
+  c->ballVelX = gxo_rng_uniform(r->seed, r->env_index, r->tick, stream, 0) > 0.5 ? BALL_SPEED : -BALL_SPEED;
+  c->ballVelY = (gxo_rng_uniform(r->seed, r->env_index, r->tick, stream, 1) - 0.5) * 2.0 * BALL_SPEED;
+}
+
+/* Envs.Pong.cs:54-70 */
+static void pong_reset(env_obj* e, const rng_ctx* r) {
+  pong_t* c = (pong_t*)e;
+  pong_reset_ball(c, r, 0);
+  c->leftPaddleY = SCREEN_HEIGHT / 2.0 - PADDLE_HEIGHT / 2.0;
+  c->rightPaddleY = SCREEN_HEIGHT / 2.0 - PADDLE_HEIGHT / 2.0;
+  c->leftScore = 0;
+  c->rightScore = 0;
+  c->steps = 0;
+}
+
+static inline double dmax(double a, double b) { return a >= b ? a : b; }
+static inline double dmin(double a, double b) { return a <= b ? a : b; }
+
+/* Envs.Pong.cs:72-157 (game state only; the frame is drawn by pong_render) */
+static int pong_step(env_obj* e, const void* action, const rng_ctx* r, double* reward, int* done) {
+  pong_t* c = (pong_t*)e;
+  int a = *(const int32_t*)action;
+  c->steps++;
+  double rew = 0.0;
+  switch (a) {
+    case 2: c->rightPaddleY = dmax(0, c->rightPaddleY - PADDLE_SPEED); break;
+    case 3: c->rightPaddleY = dmin(SCREEN_HEIGHT - PADDLE_HEIGHT, c->rightPaddleY + PADDLE_SPEED); break;
+    default: break;
+  }
+  double ballCenterY = c->ballY + BALL_SIZE / 2.0;
+  double leftPaddleCenterY = c->leftPaddleY + PADDLE_HEIGHT / 2.0;
+  if (ballCenterY < leftPaddleCenterY - 2)
+    c->leftPaddleY = dmax(0, c->leftPaddleY - PADDLE_SPEED * 0.8);
+  else if (ballCenterY > leftPaddleCenterY + 2)
+    c->leftPaddleY = dmin(SCREEN_HEIGHT - PADDLE_HEIGHT, c->leftPaddleY + PADDLE_SPEED * 0.8);
+
+  c->ballX += c->ballVelX;
+  c->ballY += c->ballVelY;
+
+  if (c->ballY <= 0 || c->ballY >= SCREEN_HEIGHT - BALL_SIZE) {
+    c->ballVelY = -c->ballVelY;
+    c->ballY = dmax(0, dmin(SCREEN_HEIGHT - BALL_SIZE, c->ballY));
+  }
+  if (c->ballX <= PADDLE_WIDTH && c->ballY + BALL_SIZE >= c->leftPaddleY &&
+      c->ballY <= c->leftPaddleY + PADDLE_HEIGHT) {
+    c->ballVelX = fabs(c->ballVelX);
+    double rel = (c->leftPaddleY + PADDLE_HEIGHT / 2.0) - (c->ballY + BALL_SIZE / 2.0);
+    c->ballVelY = -rel * 0.1;
+  }
+  if (c->ballX + BALL_SIZE >= SCREEN_WIDTH - PADDLE_WIDTH && c->ballY + BALL_SIZE >= c->rightPaddleY &&
+      c->ballY <= c->rightPaddleY + PADDLE_HEIGHT) {
+    c->ballVelX = -fabs(c->ballVelX);
+    double rel = (c->rightPaddleY + PADDLE_HEIGHT / 2.0) - (c->ballY + BALL_SIZE / 2.0);
+    c->ballVelY = -rel * 0.1;
+  }
+  if (c->ballX < 0) {
+    c->rightScore++;
+    rew = 1.0;
+    pong_reset_ball(c, r, 1);
+  } else if (c->ballX > SCREEN_WIDTH) {
+    c->leftScore++;
+    rew = -1.0;
+    pong_reset_ball(c, r, 1);
+  }
+  *done = c->leftScore >= 21 || c->rightScore >= 21 || c->steps >= 10000;
+  *reward = rew;
+  return 0;
+}
+
+/* Envs.Pong.cs:192-209 */
+static void draw_rectangle(uint8_t* screen, int x, int y, int width, int height) {
+  for (int dy = 0; dy < height; dy++)
+    for (int dx = 0; dx < width; dx++) {
+      int px = x + dx, py = y + dy;
+      if (px >= 0 && px < SCREEN_WIDTH && py >= 0 && py < SCREEN_HEIGHT) {
+        int index = (py * SCREEN_WIDTH + px) * CHANNELS;
+        screen[index] = 255;
+        screen[index + 1] = 255;
+        screen[index + 2] = 255;
+      }
+    }
+}
+
+/* Envs.Pong.cs:223-251; glyph rows from the table at :228-237 */
+static void draw_digit(uint8_t* screen, char digit, int x, int y) {
+  static const uint8_t pat[10][5][3] = {
+      {{1, 1, 1}, {1, 0, 1}, {1, 0, 1}, {1, 0, 1}, {1, 1, 1}},
+      {{0, 1, 0}, {1, 1, 0}, {0, 1, 0}, {0, 1, 0}, {1, 1, 1}},
+      {{1, 1, 1}, {0, 0, 1}, {1, 1, 1}, {1, 0, 0}, {1, 1, 1}},
+      {{1, 1, 1}, {0, 0, 1}, {1, 1, 1}, {0, 0, 1}, {1, 1, 1}},
+      {{1, 0, 1}, {1, 0, 1}, {1, 1, 1}, {0, 0, 1}, {0, 0, 1}},
+      {{1, 1, 1}, {1, 0, 0}, {1, 1, 1}, {0, 0, 1}, {1, 1, 1}},
+      {{1, 1, 1}, {1, 0, 0}, {1, 1, 1}, {1, 0, 1}, {1, 1, 1}},
+      {{1, 1, 1}, {0, 0, 1}, {0, 0, 1}, {0, 0, 1}, {0, 0, 1}},
+      {{1, 1, 1}, {1, 0, 1}, {1, 1, 1}, {1, 0, 1}, {1, 1, 1}},
+      {{1, 1, 1}, {1, 0, 1}, {1, 1, 1}, {0, 0, 1}, {1, 1, 1}}};
+  if (digit < '0' || digit > '9') return; /* '-' of a negative score: blank glyph */
+  for (int dy = 0; dy < 5; dy++)
+    for (int dx = 0; dx < 3; dx++)
+      if (pat[digit - '0'][dy][dx]) draw_rectangle(screen, x + dx, y + dy, 1, 1);
+}
+
+/* Envs.Pong.cs:211-221 */
+static void draw_score(uint8_t* screen, int score, int centerX, int y) {
+  char str[16];
+  int len = snprintf(str, sizeof str, "%d", score);
+  int startX = centerX - (len * 6) / 2;
+  for (int i = 0; i < len; i++) draw_digit(screen, str[i], startX + i * 8, y);
+}
+
+/* Envs.Pong.cs:167-190 */
+void gxo_pong_render(double ball_x, double ball_y, double left_y, double right_y, int left_score,
+                     int right_score, uint8_t* screen) {
+  memset(screen, 0, GXO_PONG_FRAME_BYTES);
+  draw_rectangle(screen, 0, (int)left_y, PADDLE_WIDTH, PADDLE_HEIGHT);
+  draw_rectangle(screen, SCREEN_WIDTH - PADDLE_WIDTH, (int)right_y, PADDLE_WIDTH, PADDLE_HEIGHT);
+  draw_rectangle(screen, (int)ball_x, (int)ball_y, BALL_SIZE, BALL_SIZE);
+  for (int y = 0; y < SCREEN_HEIGHT; y += 8) draw_rectangle(screen, SCREEN_WIDTH / 2 - 1, y, 2, 4);
+  draw_score(screen, left_score, SCREEN_WIDTH / 4, 20);
+  draw_score(screen, right_score, 3 * SCREEN_WIDTH / 4, 20);
+}
+
+static void pong_export(const env_obj* e, void* reals, int32_t* ints) {
+  const pong_t* c = (const pong_t*)e;
+  double* d = (double*)reals;
+  d[0] = c->ballX; d[1] = c->ballY; d[2] = c->ballVelX; d[3] = c->ballVelY;
+  d[4] = c->leftPaddleY; d[5] = c->rightPaddleY;
+  ints[0] = c->leftScore; ints[1] = c->rightScore; ints[2] = c->steps;
+}
+static void pong_import(env_obj* e, const void* reals, const int32_t* ints) {
+  pong_t* c = (pong_t*)e;
+  const double* d = (const double*)reals;
+  c->ballX = d[0]; c->ballY = d[1]; c->ballVelX = d[2]; c->ballVelY = d[3];
+  c->leftPaddleY = d[4]; c->rightPaddleY = d[5];
+  c->leftScore = ints[0]; c->rightScore = ints[1]; c->steps = ints[2];
+}
+static const env_vtbl pong_vt = {pong_reset, pong_step, pong_export, pong_import, sizeof(pong_t)};
+
+/* ======================================================================
+ * Wrappers and the batched driver.
+ * ====================================================================== */
+typedef struct episode_list {
+  double* ret;
+  int32_t* len;
+  size_t n, cap;
+} episode_list;
+
+static void episode_push(episode_list* l, double ret, int32_t len) {
+  if (l->n == l->cap) {
+    l->cap = l->cap ? l->cap * 2 : 4;
+    l->ret = (double*)realloc(l->ret, l->cap * sizeof(double));
+    l->len = (int32_t*)realloc(l->len, l->cap * sizeof(int32_t));
+  }
+  l->ret[l->n] = ret;
+  l->len[l->n] = len;
+  l->n++;
+}
+
+struct gxo_vec {
+  int env_id;
+  uint64_t n;
+  uint64_t seed;
+  uint32_t flags;
+  int32_t time_limit; /* Wrappers.TimeLimit.cs maxSteps; 0 = wrapper absent */
+  uint64_t env_index_base;
+  uint64_t tick;
+  env_obj** envs;
+  grid_desc* grid;
+  int n_real, real_is_f64, n_int, obs_dim, action_is_float;
+  /* Wrappers.TimeLimit.cs:9 `_steps` per env */
+  int32_t* tl_steps;
+  /* EnvWrapper.cs:27-28 `_currentReward`, `_currentLength` per env */
+  double* cur_reward;
+  int32_t* cur_length;
+  episode_list* episodes;
+};
+
+static int parse_map(grid_desc* g, const char* rows) {
+  /* rows separated by '\n' or '/'; Envs.FrozenLake.cs:31-42 */
+  int nrow = 0, ncol = 0, col = 0;
+  g->goal = -1;
+  memset(g->hole, 0, sizeof g->hole);
+  for (const char* p = rows;; p++) {
+    if (*p == '\n' || *p == '/' || *p == 0) {
+      if (col > 0) {
+        if (nrow == 0) ncol = col;
+        else if (col != ncol) return -1;
+        nrow++;
+      }
+      col = 0;
+      if (*p == 0) break;
+      continue;
+    }
+    if (nrow > 0 && col >= ncol) return -1;
+    int idx = nrow * ncol + col; /* ncol is still 0 while the first row is read */
+    if (idx >= GRID_MAX_CELLS) return -1;
+    if (*p == 'G') g->goal = idx;
+    if (*p == 'H') g->hole[idx] = 1;
+    col++;
+  }
+  if (nrow == 0 || ncol <= 0 || nrow * ncol > GRID_MAX_CELLS) return -1;
+  g->nrow = nrow;
+  g->ncol = ncol;
+  return 0;
+}
+
+static const char* const FROZENLAKE_4X4 = "SFFF/FHFH/FFFH/HFFG"; /* Envs.FrozenLake.cs:25-30 */
+
+gxo_vec* gxo_vec_create(int env_id, uint64_t num_envs, uint64_t seed, uint32_t flags, int32_t time_limit,
+                        const char* map_rows, uint64_t env_index_base) {
+  if (env_id < 0 || env_id >= GXO_NUM_ENVS) return NULL;
+  gxo_vec* v = (gxo_vec*)calloc(1, sizeof *v);
+  v->env_id = env_id;
+  v->n = num_envs;
+  v->seed = seed;
+  v->flags = flags;
+  v->time_limit = time_limit;
+  v->env_index_base = env_index_base;
+  const env_vtbl* vt = NULL;
+  switch (env_id) {
+    case GXO_CARTPOLE: vt = &cartpole_vt; v->n_real = 4; v->n_int = 1; v->obs_dim = 4; break;
+    case GXO_MOUNTAINCAR: vt = &mcar_vt; v->n_real = 2; v->n_int = 1; v->obs_dim = 2; break;
+    case GXO_MOUNTAINCAR_CONT: vt = &mcc_vt; v->n_real = 2; v->n_int = 1; v->obs_dim = 2; v->action_is_float = 1; break;
+    case GXO_PENDULUM: vt = &pendulum_vt; v->n_real = 3; v->n_int = 1; v->obs_dim = 3; v->action_is_float = 1; break;
+    case GXO_ACROBOT:
+      if (flags & GXO_ACROBOT_RK4) { vt = &acrobot64_vt; v->n_real = 4; v->real_is_f64 = 1; v->n_int = 1; v->obs_dim = 6; }
+      else { vt = &acrobot_vt; v->n_real = 6; v->n_int = 1; v->obs_dim = 6; }
+      break;
+    case GXO_FROZENLAKE:
+    case GXO_CLIFFWALKING: vt = &grid_vt; v->n_real = 0; v->n_int = 2; v->obs_dim = 1; break;
+    case GXO_TAXI: vt = &taxi_vt; v->n_real = 0; v->n_int = 2; v->obs_dim = 1; break;
+    case GXO_DUMMY: vt = &dummy_vt; v->n_real = 0; v->n_int = 2; v->obs_dim = 1; break;
+    case GXO_PONG: vt = &pong_vt; v->n_real = 6; v->real_is_f64 = 1; v->n_int = 3; v->obs_dim = GXO_PONG_FRAME_BYTES; break;
+  }
+  if (env_id == GXO_FROZENLAKE || env_id == GXO_CLIFFWALKING) {
+    grid_desc* g = (grid_desc*)calloc(1, sizeof *g);
+    if (env_id == GXO_FROZENLAKE) {
+      if (parse_map(g, map_rows && *map_rows ? map_rows : FROZENLAKE_4X4) != 0) {
+        free(g); free(v); return NULL;
+      }
+      g->start = 0;
+      g->step_limit = 100; /* Envs.FrozenLake.cs:65 */
+      g->is_cliff = 0;
+      g->slippery = (flags & GXO_SLIPPERY) != 0;
+    } else {
+      /* Envs.CliffWalking.cs:15-27 */
+      g->nrow = 4; g->ncol = 12; g->start = 36; g->goal = 47;
+      for (int c = 1; c < 11; c++) g->hole[36 + c] = 1;
+      g->step_limit = 100; /* Envs.CliffWalking.cs:49 */
+      g->is_cliff = 1;
+    }
+    v->grid = g;
+  }
+  v->envs = (env_obj**)calloc(num_envs ? num_envs : 1, sizeof(env_obj*));
+  for (uint64_t i = 0; i < num_envs; i++) {
+    env_obj* e = (env_obj*)calloc(1, vt->size);
+    e->vt = vt;
+    if (v->grid) ((grid_t*)e)->g = v->grid;
+    if (env_id == GXO_TAXI) ((taxi_t*)e)->full = (flags & GXO_TAXI_FULL) != 0;
+    v->envs[i] = e;
+  }
+  v->tl_steps = (int32_t*)calloc(num_envs ? num_envs : 1, sizeof(int32_t));
+  v->cur_reward = (double*)calloc(num_envs ? num_envs : 1, sizeof(double));
+  v->cur_length = (int32_t*)calloc(num_envs ? num_envs : 1, sizeof(int32_t));
+  v->episodes = (episode_list*)calloc(num_envs ? num_envs : 1, sizeof(episode_list));
+  if (env_id == GXO_PONG) {
+    /* The Pong constructor calls Reset() (Envs.Pong.cs:47-52).  That draw is
+     * unobservable once the batch is reset, so construction leaves tick at 0. */
+    for (uint64_t i = 0; i < num_envs; i++) {
+      rng_ctx r = {seed, env_index_base + i, 0};
+      pong_reset(v->envs[i], &r);
+    }
+  }
+  return v;
+}
+
+void gxo_vec_destroy(gxo_vec* v) {
+  if (!v) return;
+  for (uint64_t i = 0; i < v->n; i++) {
+    free(v->envs[i]);
+    free(v->episodes[i].ret);
+    free(v->episodes[i].len);
+  }
+  free(v->envs);
+  free(v->grid);
+  free(v->tl_steps);
+  free(v->cur_reward);
+  free(v->cur_length);
+  free(v->episodes);
+  free(v);
+}
+
+uint64_t gxo_vec_num_envs(const gxo_vec* v) { return v->n; } /* VectorEnv.cs:13 */
+int gxo_vec_obs_dim(const gxo_vec* v) { return v->obs_dim; }
+int gxo_vec_n_real(const gxo_vec* v) { return v->n_real; }
+int gxo_vec_real_is_f64(const gxo_vec* v) { return v->real_is_f64; }
+int gxo_vec_n_int(const gxo_vec* v) { return v->n_int; }
+uint64_t gxo_vec_tick(const gxo_vec* v) { return v->tick; }
+size_t gxo_vec_state_bytes(const gxo_vec* v) {
+  return (size_t)v->n * ((size_t)v->n_real * (v->real_is_f64 ? 8 : 4) + (size_t)v->n_int * 4);
+}
+
+/* Reset through the wrapper chain RecordEpisodeStatistics(TimeLimit(env)):
+ * EnvWrapper.cs:32-42 then Wrappers.TimeLimit.cs:17-21 then the env. */
+static void wrapped_reset(gxo_vec* v, uint64_t i, const rng_ctx* r) {
+  if (v->flags & GXO_RECORD_STATS) {
+    if (v->cur_length[i] > 0) episode_push(&v->episodes[i], v->cur_reward[i], v->cur_length[i]);
+    v->cur_reward[i] = 0;
+    v->cur_length[i] = 0;
+  }
+  v->tl_steps[i] = 0;
+  v->envs[i]->vt->reset(v->envs[i], r);
+}
+
+/* VectorEnv.cs:20-26 */
+void gxo_vec_reset(gxo_vec* v) {
+  for (uint64_t i = 0; i < v->n; i++) {
+    rng_ctx r = {v->seed, v->env_index_base + i, v->tick};
+    wrapped_reset(v, i, &r);
+  }
+  v->tick++;
+}
+
+static int vec_step_impl(gxo_vec* v, const void* actions, int random_policy, void* actions_out,
+                         double* reward, uint8_t* done, uint8_t* truncated) {
+  /* VectorEnv.cs:28-34: sequential loop, one virtual Step per env */
+  for (uint64_t i = 0; i < v->n; i++) {
+    rng_ctx r = {v->seed, v->env_index_base + i, v->tick};
+    int32_t ai = 0;
+    float af = 0.0f;
+    const void* ap;
+    if (random_policy) {
+      double u;
+      switch (v->env_id) {
+        case GXO_MOUNTAINCAR_CONT: /* Box([-1],[1]) Envs.MountainCarContinuous.cs:12 */
+          u = gxo_rng_uniform(r.seed, r.env_index, r.tick, 2, 0);
+          af = gxo_box_sample(u, -1.0f, 1.0f);
+          break;
+        case GXO_PENDULUM: /* Box([-2],[2]) Envs.Pendulum.cs:12 */
+          u = gxo_rng_uniform(r.seed, r.env_index, r.tick, 2, 0);
+          af = gxo_box_sample(u, -2.0f, 2.0f);
+          break;
+        default: {
+          static const int nact[GXO_NUM_ENVS] = {2, 3, 0, 0, 3, 4, 6, 4, 4, 3};
+          ai = gxo_rng_below(r.seed, r.env_index, r.tick, 2, 0, nact[v->env_id]);
+        }
+      }
+      if (v->action_is_float) {
+        ap = &af;
+        if (actions_out) ((float*)actions_out)[i] = af;
+      } else {
+        ap = &ai;
+        if (actions_out) ((int32_t*)actions_out)[i] = ai;
+      }
+    } else {
+      ap = v->action_is_float ? (const void*)((const float*)actions + i) : (const void*)((const int32_t*)actions + i);
+    }
+    double rew = 0;
+    int d = 0, trunc = 0;
+    if (v->envs[i]->vt->step(v->envs[i], ap, &r, &rew, &d) != 0) return -1;
+    /* Wrappers.TimeLimit.cs:23-33 */
+    v->tl_steps[i]++;
+    if (v->time_limit > 0 && v->tl_steps[i] >= v->time_limit) {
+      d = 1;
+      trunc = 1;
+    }
+    /* EnvWrapper.cs:44-57 */
+    if (v->flags & GXO_RECORD_STATS) {
+      v->cur_reward[i] += rew;
+      v->cur_length[i]++;
+      if (d) {
+        episode_push(&v->episodes[i], v->cur_reward[i], v->cur_length[i]);
+        v->cur_reward[i] = 0;
+        v->cur_length[i] = 0;
+      }
+    }
+    if (reward) reward[i] = rew;
+    if (done) done[i] = (uint8_t)d;
+    if (truncated) truncated[i] = (uint8_t)trunc;
+    if (d && (v->flags & GXO_AUTORESET)) wrapped_reset(v, i, &r);
+  }
+  v->tick++;
+  return 0;
+}
+
+int gxo_vec_step(gxo_vec* v, const void* actions, double* reward, uint8_t* done, uint8_t* truncated) {
+  return vec_step_impl(v, actions, 0, NULL, reward, done, truncated);
+}
+int gxo_vec_step_random(gxo_vec* v, void* actions_out, double* reward, uint8_t* done, uint8_t* truncated) {
+  return vec_step_impl(v, NULL, 1, actions_out, reward, done, truncated);
+}
+
+void gxo_vec_get_state(const gxo_vec* v, void* buf) {
+  size_t rsz = v->real_is_f64 ? 8 : 4;
+  char* reals = (char*)buf;
+  int32_t* ints = (int32_t*)(reals + (size_t)v->n * v->n_real * rsz);
+  double tmp[8];
+  int32_t itmp[4];
+  for (uint64_t i = 0; i < v->n; i++) {
+    v->envs[i]->vt->export_state(v->envs[i], tmp, itmp);
+    for (int k = 0; k < v->n_real; k++)
+      memcpy(reals + ((size_t)k * v->n + i) * rsz, (char*)tmp + (size_t)k * rsz, rsz);
+    for (int k = 0; k < v->n_int; k++) ints[(size_t)k * v->n + i] = itmp[k];
+  }
+}
+
+void gxo_vec_set_state(gxo_vec* v, const void* buf) {
+  size_t rsz = v->real_is_f64 ? 8 : 4;
+  const char* reals = (const char*)buf;
+  const int32_t* ints = (const int32_t*)(reals + (size_t)v->n * v->n_real * rsz);
+  double tmp[8];
+  int32_t itmp[4];
+  for (uint64_t i = 0; i < v->n; i++) {
+    for (int k = 0; k < v->n_real; k++)
+      memcpy((char*)tmp + (size_t)k * rsz, reals + ((size_t)k * v->n + i) * rsz, rsz);
+    for (int k = 0; k < v->n_int; k++) itmp[k] = ints[(size_t)k * v->n + i];
+    v->envs[i]->vt->import_state(v->envs[i], tmp, itmp);
+    /* the TimeLimit counter equals the env's own step counter at all times */
+    v->tl_steps[i] = itmp[v->n_int - 1];
+  }
+}
+
+void gxo_vec_get_obs(const gxo_vec* v, void* buf) {
+  double tmp[8];
+  int32_t itmp[4];
+  for (uint64_t i = 0; i < v->n; i++) {
+    v->envs[i]->vt->export_state(v->envs[i], tmp, itmp);
+    if (v->env_id == GXO_PONG) {
+      gxo_pong_render(tmp[0], tmp[1], tmp[4], tmp[5], itmp[0], itmp[1],
+                      (uint8_t*)buf + (size_t)i * GXO_PONG_FRAME_BYTES);
+    } else if (v->env_id == GXO_ACROBOT && v->real_is_f64) {
+      float* o = (float*)buf;
+      o[0 * v->n + i] = (float)cos(tmp[0]);
+      o[1 * v->n + i] = (float)sin(tmp[0]);
+      o[2 * v->n + i] = (float)cos(tmp[1]);
+      o[3 * v->n + i] = (float)sin(tmp[1]);
+      o[4 * v->n + i] = (float)tmp[2];
+      o[5 * v->n + i] = (float)tmp[3];
+    } else if (v->n_real > 0) {
+      for (int k = 0; k < v->n_real; k++) ((float*)buf)[(size_t)k * v->n + i] = ((float*)tmp)[k];
+    } else {
+      ((int32_t*)buf)[i] = itmp[0];
+    }
+  }
+}
+
+void gxo_vec_stats(const gxo_vec* v, gxo_stats* out) {
+  gxo_stats s = {0, 0.0, 0, 0.0, INFINITY, -INFINITY};
+  for (uint64_t i = 0; i < v->n; i++) {
+    const episode_list* l = &v->episodes[i];
+    for (size_t k = 0; k < l->n; k++) {
+      s.episodes++;
+      s.sum_return += l->ret[k];
+      s.sum_length += l->len[k];
+      s.sum_return_sq += l->ret[k] * l->ret[k];
+      if (l->ret[k] < s.min_return) s.min_return = l->ret[k];
+      if (l->ret[k] > s.max_return) s.max_return = l->ret[k];
+    }
+  }
+  *out = s;
+}
+
+size_t gxo_vec_episode_count(const gxo_vec* v, uint64_t env) { return v->episodes[env].n; }
+void gxo_vec_episode_get(const gxo_vec* v, uint64_t env, size_t k, double* ret, int32_t* len) {
+  *ret = v->episodes[env].ret[k];
+  *len = v->episodes[env].len[k];
+}
+
+/* ======================================================================
+ * CPU baseline, shaped like the reference: a list of heap objects, one
+ * virtual Step per env per batch step, a freshly allocated result list per
+ * call (VectorEnv.cs:28-34), single thread.  It omits the per-env-step
+ * Dictionary allocation and tuple boxing of the reference
+ * (Envs.CartPole.cs:73, VectorEnv.cs:30-32), so it flatters the reference.
+ * ====================================================================== */
+typedef struct step_result {
+  double state[6];
+  double reward;
+  int done;
+  void* info;
+} step_result;
+
+double gxo_bench_reference_shaped(int env_id, uint64_t num_envs, int steps, uint64_t seed, uint64_t* env_steps,
+                                  double* checksum) {
+  gxo_vec* v = gxo_vec_create(env_id, num_envs, seed, 0, 0, NULL, 0);
+  if (!v) return -1.0;
+  gxo_vec_reset(v);
+  void* actions = malloc(num_envs * 4);
+  static const int nact[GXO_NUM_ENVS] = {2, 3, 0, 0, 3, 4, 6, 4, 4, 3};
+  for (uint64_t i = 0; i < num_envs; i++) {
+    if (v->action_is_float) {
+      float lim = env_id == GXO_PENDULUM ? 2.0f : 1.0f;
+      ((float*)actions)[i] = gxo_box_sample(gxo_rng_uniform(seed, i, 0, 2, 0), -lim, lim);
+    } else {
+      ((int32_t*)actions)[i] = gxo_rng_below(seed, i, 0, 2, 0, nact[env_id]);
+    }
+  }
+  /* every Pong object owns its 210x160x3 `_screen` (Envs.Pong.cs:49) */
+  uint8_t* screens = env_id == GXO_PONG ? (uint8_t*)malloc(num_envs * (size_t)GXO_PONG_FRAME_BYTES) : NULL;
+  double acc = 0.0;
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (int s = 0; s < steps; s++) {
+    step_result* results = (step_result*)malloc(num_envs * sizeof(step_result));
+    for (uint64_t i = 0; i < num_envs; i++) {
+      rng_ctx r = {seed, i, v->tick};
+      env_obj* e = v->envs[i];
+      const void* ap = (const char*)actions + i * 4;
+      int32_t ints[4];
+      e->vt->step(e, ap, &r, &results[i].reward, &results[i].done);
+      e->vt->export_state(e, results[i].state, ints);
+      results[i].info = NULL;
+      if (results[i].done) e->vt->reset(e, &r); /* the caller's episode loop */
+      if (screens) { /* Envs.Pong.cs:146 RenderScreen() on every step */
+        const double* st = results[i].state;
+        e->vt->export_state(e, results[i].state, ints);
+        gxo_pong_render(st[0], st[1], st[4], st[5], ints[0], ints[1], screens + i * (size_t)GXO_PONG_FRAME_BYTES);
+        acc += screens[i * (size_t)GXO_PONG_FRAME_BYTES + 60];
+      }
+    }
+    v->tick++;
+    acc += results[num_envs - 1].reward + results[0].state[0];
+    free(results);
+  }
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  if (env_steps) *env_steps = num_envs * (uint64_t)steps;
+  if (checksum) *checksum = acc;
+  free(actions);
+  free(screens);
+  gxo_vec_destroy(v);
+  return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}

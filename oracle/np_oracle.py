@@ -1,0 +1,387 @@
+"""Second, independent restatement of the reference step path in numpy.
+
+TEST INFRASTRUCTURE ONLY.  It exists to pin oracle/gym_oracle.c: the
+reference's own tests hold no numeric vectors for these environments, so two
+restatements written separately from the reference source (this one is
+vectorised over the batch and structured around arrays, the C one around
+per-env objects) must agree bit-for-bit (tests/test_oracle_cross.py).
+
+numpy float32 arithmetic rounds to binary32 after every operation, which is
+what CoreCLR does for C# `float`.  Math.Sin/Cos/Atan2 are evaluated with
+Python's math module (the platform libm, as CoreCLR uses on Linux) on the
+float64 value and rounded once to float32 -- numpy's own vectorised sin/cos
+are a different implementation and are deliberately not used.
+
+Citations are into the reference's Gymnasium/ directory.
+"""
+import math
+
+import numpy as np
+
+f32 = np.float32
+f64 = np.float64
+M32 = np.uint64(0xFFFFFFFF)
+
+
+# --------------------------------------------------------------- counter RNG
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Vectorised Philox4x32-10 on uint64 arrays holding 32-bit values."""
+    c0, c1, c2, c3 = (np.asarray(x, np.uint64) for x in (c0, c1, c2, c3))
+    k0 = np.uint64(k0)
+    k1 = np.uint64(k1)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c0
+        p1 = np.uint64(0xCD9E8D57) * c2
+        n0 = (p1 >> np.uint64(32)) ^ c1 ^ k0
+        n1 = p1 & M32
+        n2 = (p0 >> np.uint64(32)) ^ c3 ^ k1
+        n3 = p0 & M32
+        c0, c1, c2, c3 = n0, n1, n2, n3
+        k0 = (k0 + np.uint64(0x9E3779B9)) & M32
+        k1 = (k1 + np.uint64(0xBB67AE85)) & M32
+    return c0, c1, c2, c3
+
+
+def rng_u64(seed, env, tick, stream, draw):
+    env = np.asarray(env, np.uint64)
+    tick = int(tick)
+    c3 = np.uint64((stream << 24) | (((tick >> 32) & 0xFF) << 16) | ((draw >> 1) & 0xFFFF))
+    o = philox4x32_10(env & M32, env >> np.uint64(32), np.full_like(env, tick & 0xFFFFFFFF),
+                      np.full_like(env, c3), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    lo, hi = (o[2], o[3]) if (draw & 1) else (o[0], o[1])
+    return (hi << np.uint64(32)) | lo
+
+
+def rng_uniform(seed, env, tick, stream, draw):
+    return (rng_u64(seed, env, tick, stream, draw) >> np.uint64(11)).astype(f64) * 2.0 ** -53
+
+
+def rng_below(seed, env, tick, stream, draw, n):
+    hi = rng_u64(seed, env, tick, stream, draw) >> np.uint64(32)
+    return ((hi * np.uint64(n)) >> np.uint64(32)).astype(np.int32)
+
+
+# -------------------------------------------------------------- libm helpers
+def _map1(fn, x):
+    x = np.asarray(x, f64)
+    return np.array([fn(float(v)) for v in x.ravel()], f64).reshape(x.shape)
+
+
+def cos32(x64):
+    return _map1(math.cos, x64).astype(f32)
+
+
+def sin32(x64):
+    return _map1(math.sin, x64).astype(f32)
+
+
+def atan2_32(y, x):
+    y = np.asarray(y, f64)
+    x = np.asarray(x, f64)
+    return np.array([math.atan2(float(a), float(b)) for a, b in zip(y.ravel(), x.ravel())], f64).reshape(y.shape).astype(f32)
+
+
+def clamp(v, lo, hi):
+    # Math.Clamp: value < min -> min; value > max -> max; else value
+    return np.where(v < lo, lo, np.where(v > hi, hi, v)).astype(v.dtype)
+
+
+# ---------------------------------------------------------------- CartPole
+def cartpole_reset(seed, env, tick):
+    """Envs.CartPole.cs:22-32"""
+    return np.stack([(rng_uniform(seed, env, tick, 0, i) * 0.1 - 0.05).astype(f32) for i in range(4)])
+
+
+def cartpole_step(s, steps, action):
+    """Envs.CartPole.cs:34-75.  s: float32 [4, N]"""
+    gravity, masscart, masspole = f32(9.8), f32(1.0), f32(0.1)
+    total_mass = f32(masscart + masspole)
+    length = f32(0.5)
+    polemass_length = f32(masspole * length)
+    force_mag, tau = f32(10.0), f32(0.02)
+    thr = f32(f32(f32(12) * f32(math.pi)) / f32(180))
+    x_thr = f32(2.4)
+    x, xd, th, thd = (s[i].astype(f32) for i in range(4))
+    force = np.where(np.asarray(action) == 1, force_mag, -force_mag).astype(f32)
+    c = cos32(th.astype(f64))
+    sn = sin32(th.astype(f64))
+    temp = (force + polemass_length * thd * thd * sn) / total_mass
+    thacc = (gravity * sn - c * temp) / (length * (f32(f32(4.0) / f32(3.0)) - masspole * c * c / total_mass))
+    xacc = temp - polemass_length * thacc * c / total_mass
+    x = x + tau * xd
+    xd = xd + tau * xacc
+    th = th + tau * thd
+    thd = thd + tau * thacc
+    steps = steps + 1
+    done = (x < -x_thr) | (x > x_thr) | (th < -thr) | (th > thr) | (steps >= 500)
+    reward = np.where(done, 0.0, 1.0)
+    return np.stack([x, xd, th, thd]).astype(f32), steps, reward, done
+
+
+# ------------------------------------------------------------- MountainCar
+def mountaincar_reset(seed, env, tick):
+    """Envs.MountainCar.cs:22-30 / Envs.MountainCarContinuous.cs:19-27"""
+    p = (rng_uniform(seed, env, tick, 0, 0) * 0.2 - 0.6).astype(f32)
+    return np.stack([p, np.zeros_like(p)])
+
+
+def _mcar_tail(p, v, goal):
+    v = clamp(v, f32(-0.07), f32(0.07))
+    p = (p + v).astype(f32)
+    wall = p < f32(-1.2)
+    p = np.where(wall, f32(-1.2), p).astype(f32)
+    v = np.where(wall, f32(0.0), v).astype(f32)
+    return p, v, p >= f32(goal)
+
+
+def mountaincar_step(s, steps, action):
+    """Envs.MountainCar.cs:32-50"""
+    p, v = s[0].astype(f32), s[1].astype(f32)
+    force = (np.asarray(action, np.int64) - 1).astype(f32)
+    v = v + (f32(0.001) * force - f32(0.0025) * cos32((f32(3) * p).astype(f64)))
+    p, v, done = _mcar_tail(p, v.astype(f32), 0.5)
+    return np.stack([p, v]), steps + 1, np.where(done, 0.0, -1.0), done
+
+
+def mountaincar_cont_step(s, steps, action):
+    """Envs.MountainCarContinuous.cs:29-49"""
+    p, v = s[0].astype(f32), s[1].astype(f32)
+    force = clamp(np.asarray(action, f32), f32(-1.0), f32(1.0))
+    v = v + (force * f32(0.0015) - f32(0.0025) * cos32((f32(3) * p).astype(f64)))
+    p, v, done = _mcar_tail(p, v.astype(f32), 0.45)
+    reward = v.astype(f64) * 0.1
+    reward = np.where(done, reward + 100.0, reward)
+    return np.stack([p, v]), steps + 1, reward, done
+
+
+# ---------------------------------------------------------------- Pendulum
+def pendulum_reset(seed, env, tick):
+    """Envs.Pendulum.cs:19-28"""
+    th = (rng_uniform(seed, env, tick, 0, 0) * 2 * math.pi - math.pi).astype(f32)
+    thd = (rng_uniform(seed, env, tick, 0, 1) * 1 - 0.5).astype(f32)
+    return np.stack([cos32(th.astype(f64)), sin32(th.astype(f64)), thd])
+
+
+def pendulum_step(s, steps, action):
+    """Envs.Pendulum.cs:30-60"""
+    dt = f32(0.05)
+    th = atan2_32(s[1], s[0])
+    thd = s[2].astype(f32)
+    u = clamp(np.asarray(action, f32), f32(-2.0), f32(2.0))
+    k1 = f32(f32(-3 * f32(10.0)) / f32(2 * f32(1.0)))  # -3*g/(2*l)
+    k2 = f32(f32(3.0) / f32(1.0))  # 3.0f/(m*l*l)
+    nthd = thd + (k1 * sin32(th.astype(f64) + math.pi) + k2 * u) * dt
+    nthd = clamp(nthd.astype(f32), f32(-8.0), f32(8.0))
+    nth = (th + nthd * dt).astype(f32)
+    reward = -((th * th).astype(f64) + 0.1 * thd.astype(f64) * thd.astype(f64) + 0.001 * u.astype(f64) * u.astype(f64))
+    ns = np.stack([cos32(nth.astype(f64)), sin32(nth.astype(f64)), nthd])
+    return ns, steps + 1, reward, np.zeros(th.shape, bool)
+
+
+# ----------------------------------------------------------------- Acrobot
+def acrobot_reset(seed, env, tick):
+    """Envs.Acrobot.cs:22-28"""
+    return np.stack([(rng_uniform(seed, env, tick, 0, i) * 0.1 - 0.05).astype(f32) for i in range(6)])
+
+
+def acrobot_step(s, steps, action):
+    """Envs.Acrobot.cs:30-91"""
+    action = np.asarray(action)
+    if ((action < 0) | (action > 2)).any():
+        raise IndexError("torque[action]")  # Envs.Acrobot.cs:51
+    one, half, g, dt = f32(1.0), f32(0.5), f32(9.8), f32(0.2)
+    mv1 = f32(f32(4) * f32(math.pi))
+    mv2 = f32(f32(9) * f32(math.pi))
+    t1 = atan2_32(s[1], s[0])
+    t2 = atan2_32(s[3], s[2])
+    w1, w2 = s[4].astype(f32), s[5].astype(f32)
+    u = (action.astype(np.int64) - 1).astype(f32)
+    c2 = cos32(t2.astype(f64))
+    s2 = sin32(t2.astype(f64))
+    lc2 = f32(half * half)  # lc^2 = 0.25
+    d1 = f32(one * half * half) + one * (f32(one * one + lc2) + f32(2 * one * half) * c2) + one + one
+    d2 = one * (lc2 + f32(one * half) * c2) + one
+    phi2 = f32(f32(one * half) * g) * cos32((t1 + t2).astype(f64) - math.pi / 2.0)
+    phi1 = (f32(-one * one * half) * w2 * w2 * s2 - f32(2 * one * one * half) * w2 * w1 * s2
+            + f32(f32(one * half + one * one) * g) * cos32(t1.astype(f64) - math.pi / 2.0) + phi2)
+    a2 = (u + d2 / d1 * phi1 - f32(one * one * half) * w1 * w1 * s2 - phi2) / (f32(f32(one * half * half) + one) - d2 * d2 / d1)
+    a1 = -(d2 * a2 + phi1) / d1
+    w1 = clamp((w1 + dt * a1).astype(f32), -mv1, mv1)
+    w2 = clamp((w2 + dt * a2).astype(f32), -mv2, mv2)
+    t1 = (t1 + dt * w1).astype(f32)
+    t2 = (t2 + dt * w2).astype(f32)
+    ct1 = cos32(t1.astype(f64))
+    ns = np.stack([ct1, sin32(t1.astype(f64)), cos32(t2.astype(f64)), sin32(t2.astype(f64)), w1, w2]).astype(f32)
+    steps = steps + 1
+    tip = -one * ct1 - one * cos32((t1 + t2).astype(f64))
+    done = (tip > one) | (steps >= 500)
+    return ns, steps, np.where(done, 0.0, -1.0), done
+
+
+# -------------------------------------------------------------- grid worlds
+def parse_map(rows):
+    """Envs.FrozenLake.cs:31-42 -> (nrow, ncol, goal, hole mask)"""
+    nrow, ncol = len(rows), len(rows[0])
+    flat = "".join(rows)
+    goal = flat.rfind("G")  # the loop keeps the last 'G'
+    holes = np.array([ch == "H" for ch in flat], bool)
+    return nrow, ncol, goal, holes
+
+
+def grid_move(state, action, nrow, ncol):
+    row, col = state // ncol, state % ncol
+    a = np.asarray(action)
+    col = np.where(a == 0, np.maximum(col - 1, 0), col)
+    row = np.where(a == 1, np.minimum(row + 1, nrow - 1), row)
+    col = np.where(a == 2, np.minimum(col + 1, ncol - 1), col)
+    row = np.where(a == 3, np.maximum(row - 1, 0), row)
+    return (row * ncol + col).astype(np.int32)
+
+
+def frozenlake_step(state, steps, action, rows=("SFFF", "FHFH", "FFFH", "HFFG")):
+    """Envs.FrozenLake.cs:52-69"""
+    nrow, ncol, goal, holes = parse_map(rows)
+    ns = grid_move(state, action, nrow, ncol)
+    steps = steps + 1
+    done = (ns == goal) | holes[ns] | (steps >= 100)
+    return ns, steps, np.where(ns == goal, 1.0, 0.0), done
+
+
+def cliffwalking_step(state, steps, action):
+    """Envs.CliffWalking.cs:36-54"""
+    ns = grid_move(state, action, 4, 12)
+    steps = steps + 1
+    cliff = (ns >= 37) & (ns <= 46)
+    done = (ns == 47) | cliff | (steps >= 100)
+    reward = np.where(ns == 47, 0.0, np.where(cliff, -100.0, -1.0))
+    return ns, steps, reward, done
+
+
+def taxi_step(state, steps, action):
+    """Envs.Taxi.cs:25-33 (a stub in the reference)"""
+    steps = steps + 1
+    return state, steps, np.full(state.shape, -1.0), steps >= 200
+
+
+def dummy_step(state, steps, action):
+    """DummyEnv.cs:23-30"""
+    ns = (state + np.asarray(action, np.int32)).astype(np.int32)
+    return ns, steps + 1, ns.astype(f64), ns >= 10
+
+
+# -------------------------------------------------------------------- Pong
+def pong_reset_ball(seed, env, tick, stream):
+    """Envs.Pong.cs:159-165"""
+    n = np.asarray(env).shape
+    vx = np.where(rng_uniform(seed, env, tick, stream, 0) > 0.5, 3.0, -3.0)
+    vy = (rng_uniform(seed, env, tick, stream, 1) - 0.5) * 2.0 * 3.0
+    return np.full(n, 80.0), np.full(n, 105.0), vx, vy
+
+
+def pong_step(st, ints, action, seed, env, tick):
+    """Envs.Pong.cs:72-157.  st: float64 [6, N] (ballX, ballY, velX, velY,
+    leftY, rightY); ints: int32 [3, N] (leftScore, rightScore, steps)."""
+    bx, by, vx, vy, ly, ry = (st[i].astype(f64).copy() for i in range(6))
+    ls, rs, steps = (ints[i].astype(np.int32).copy() for i in range(3))
+    a = np.asarray(action)
+    steps = steps + 1
+    ry = np.where(a == 2, np.maximum(0.0, ry - 4.0), ry)
+    ry = np.where(a == 3, np.minimum(195.0, ry + 4.0), ry)
+    bc, lc = by + 1.0, ly + 7.5
+    up, down = bc < lc - 2, bc > lc + 2
+    ly = np.where(up, np.maximum(0.0, ly - 4.0 * 0.8), np.where(down, np.minimum(195.0, ly + 4.0 * 0.8), ly))
+    bx = bx + vx
+    by = by + vy
+    wall = (by <= 0) | (by >= 208)
+    vy = np.where(wall, -vy, vy)
+    by = np.where(wall, np.maximum(0.0, np.minimum(208.0, by)), by)
+    hitl = (bx <= 2) & (by + 2 >= ly) & (by <= ly + 15)
+    vx = np.where(hitl, np.abs(vx), vx)
+    vy = np.where(hitl, -((ly + 7.5) - (by + 1.0)) * 0.1, vy)
+    hitr = (bx + 2 >= 158) & (by + 2 >= ry) & (by <= ry + 15)
+    vx = np.where(hitr, -np.abs(vx), vx)
+    vy = np.where(hitr, -((ry + 7.5) - (by + 1.0)) * 0.1, vy)
+    sr = bx < 0
+    sl = (~sr) & (bx > 160)
+    rs = rs + sr.astype(np.int32)
+    ls = ls + sl.astype(np.int32)
+    reward = np.where(sr, 1.0, np.where(sl, -1.0, 0.0))
+    nbx, nby, nvx, nvy = pong_reset_ball(seed, env, tick, 1)
+    rb = sr | sl
+    bx, by, vx, vy = (np.where(rb, n, o) for n, o in ((nbx, bx), (nby, by), (nvx, vx), (nvy, vy)))
+    done = (ls >= 21) | (rs >= 21) | (steps >= 10000)
+    return np.stack([bx, by, vx, vy, ly, ry]), np.stack([ls, rs, steps]), reward, done
+
+
+_GLYPHS = [
+    ["111", "101", "101", "101", "111"], ["010", "110", "010", "010", "111"],
+    ["111", "001", "111", "100", "111"], ["111", "001", "111", "001", "111"],
+    ["101", "101", "111", "001", "001"], ["111", "100", "111", "001", "111"],
+    ["111", "100", "111", "101", "111"], ["111", "001", "001", "001", "001"],
+    ["111", "101", "111", "101", "111"], ["111", "101", "111", "001", "111"],
+]  # Envs.Pong.cs:228-237
+
+
+def pong_frame(bx, by, ly, ry, ls, rs):
+    """Envs.Pong.cs:167-251 as a boolean mask (every drawn pixel is white, so
+    draw order is irrelevant), expanded to HWC bytes."""
+    m = np.zeros((210, 160), bool)
+
+    def rect(x, y, w, h):
+        m[max(y, 0):max(min(y + h, 210), 0), max(x, 0):max(min(x + w, 160), 0)] = True
+
+    rect(0, int(ly), 2, 15)
+    rect(158, int(ry), 2, 15)
+    rect(int(bx), int(by), 2, 2)
+    for y in range(0, 210, 8):
+        rect(79, y, 2, 4)
+    for score, cx in ((ls, 40), (rs, 120)):
+        txt = str(int(score))
+        x0 = cx - (len(txt) * 6) // 2
+        for i, ch in enumerate(txt):
+            if not ch.isdigit():
+                continue
+            for dy, row in enumerate(_GLYPHS[int(ch)]):
+                for dx, bit in enumerate(row):
+                    if bit == "1":
+                        rect(x0 + 8 * i + dx, 20 + dy, 1, 1)
+    return np.repeat((m.astype(np.uint8) * 255).reshape(-1), 3)
+
+
+# ---------------------------------------------------------------- wrappers
+class RecordEpisodeStatistics:
+    """EnvWrapper.cs:23-58 for one env index; `step` takes the inner result."""
+
+    def __init__(self):
+        self.episode_rewards, self.episode_lengths = [], []
+        self._r, self._n = 0.0, 0
+
+    def reset(self):
+        if self._n > 0:
+            self.episode_rewards.append(self._r)
+            self.episode_lengths.append(self._n)
+        self._r, self._n = 0.0, 0
+
+    def step(self, reward, done):
+        self._r += reward
+        self._n += 1
+        if done:
+            self.episode_rewards.append(self._r)
+            self.episode_lengths.append(self._n)
+            self._r, self._n = 0.0, 0
+
+
+class TimeLimit:
+    """Wrappers.TimeLimit.cs:6-34; `step` returns (done, truncated)."""
+
+    def __init__(self, max_steps):
+        self.max_steps, self._steps = max_steps, 0
+
+    def reset(self):
+        self._steps = 0
+
+    def step(self, done):
+        self._steps += 1
+        if self._steps >= self.max_steps:
+            return True, True
+        return bool(done), False

@@ -1,0 +1,153 @@
+"""The C oracle and the independent numpy restatement must agree bit-for-bit.
+
+This is the compensation for the reference holding no numeric vectors on the
+step path: two restatements written separately from the same source lines.
+"""
+import numpy as np
+import pytest
+
+from oracle import np_oracle as NP
+
+N = 1500
+STEPS = 40
+SEED = 0xC0FFEE
+
+
+def bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view({4: np.uint32, 8: np.uint64}[a.dtype.itemsize])
+
+
+CLASSIC = [
+    ("CARTPOLE", NP.cartpole_reset, NP.cartpole_step, 2),
+    ("MOUNTAINCAR", NP.mountaincar_reset, NP.mountaincar_step, 3),
+    ("MOUNTAINCAR_CONT", NP.mountaincar_reset, NP.mountaincar_cont_step, None),
+    ("PENDULUM", NP.pendulum_reset, NP.pendulum_step, None),
+    ("ACROBOT", NP.acrobot_reset, NP.acrobot_step, 3),
+]
+
+
+@pytest.mark.parametrize("name,resetf,stepf,nact", CLASSIC, ids=[c[0] for c in CLASSIC])
+def test_classic_control_bitwise(oracle, name, resetf, stepf, nact):
+    eid = getattr(oracle, name)
+    v = oracle.OracleVec(eid, N, seed=SEED, env_index_base=10)
+    v.reset()
+    reals, ints = v.get_state()
+    assert np.array_equal(bits(reals), bits(resetf(SEED, np.arange(N, dtype=np.uint64) + 10, 0)))
+    rng = np.random.default_rng(1)
+    s, st = reals.copy(), ints[0].copy()
+    for t in range(STEPS):
+        if nact is None:
+            a = (rng.random(N) * 6 - 3).astype(np.float32)  # exercises the clamp
+        else:
+            a = rng.integers(0, nact, N).astype(np.int32)
+        rew, done, _ = v.step(a)
+        s, st, rew2, done2 = stepf(s, st, a)
+        reals, ints = v.get_state()
+        assert np.array_equal(bits(reals), bits(s)), (name, t)
+        assert np.array_equal(ints[0], st)
+        assert np.array_equal(bits(rew), bits(np.asarray(rew2, np.float64))), (name, t)
+        assert np.array_equal(done.astype(bool), done2)
+
+
+def test_classic_control_wide_states(oracle):
+    """Random states far outside the reset range: large angles, saturated velocities."""
+    rng = np.random.default_rng(2)
+    for name, _, stepf, nact in CLASSIC:
+        eid = getattr(oracle, name)
+        v = oracle.OracleVec(eid, N)
+        v.reset()
+        dim = v.n_real
+        s = (rng.standard_normal((dim, N)) * np.array([3, 3, 50, 20, 20, 20][:dim])[:, None]).astype(np.float32)
+        st = rng.integers(0, 600, N).astype(np.int32)
+        v.set_state(s, st[None])
+        a = (rng.random(N) * 6 - 3).astype(np.float32) if nact is None else rng.integers(0, nact, N).astype(np.int32)
+        rew, done, _ = v.step(a)
+        s2, st2, rew2, done2 = stepf(s, st, a)
+        reals, ints = v.get_state()
+        assert np.array_equal(bits(reals), bits(s2)), name
+        assert np.array_equal(bits(rew), bits(np.asarray(rew2, np.float64))), name
+        assert np.array_equal(done.astype(bool), done2), name
+
+
+def test_grid_worlds_bitwise(oracle):
+    rng = np.random.default_rng(3)
+    maps = [None, ["SFFFFFFF", "FFFFFFFF", "FFFHFFFF", "FFFFFHFF", "FFFHFFFF", "FHHFFFHF", "FHFFHFHF", "FFFHFFFG"], ["SFG", "HFF"]]
+    for rows in maps:
+        v = oracle.OracleVec(oracle.FROZENLAKE, N, map_rows=rows)
+        v.reset()
+        st = np.zeros(N, np.int32); steps = np.zeros(N, np.int32)
+        kw = {} if rows is None else {"rows": rows}
+        for t in range(60):
+            a = rng.integers(-1, 6, N).astype(np.int32)
+            rew, done, _ = v.step(a)
+            st, steps, rew2, done2 = NP.frozenlake_step(st, steps, a, **kw)
+            assert np.array_equal(v.get_obs(), st) and np.array_equal(rew, rew2) and np.array_equal(done.astype(bool), done2)
+    v = oracle.OracleVec(oracle.CLIFFWALKING, N)
+    v.reset()
+    st = np.full(N, 36, np.int32); steps = np.zeros(N, np.int32)
+    for t in range(120):
+        a = rng.integers(0, 4, N).astype(np.int32)
+        rew, done, _ = v.step(a)
+        st, steps, rew2, done2 = NP.cliffwalking_step(st, steps, a)
+        assert np.array_equal(v.get_obs(), st) and np.array_equal(rew, rew2) and np.array_equal(done.astype(bool), done2)
+
+
+def test_pong_bitwise(oracle):
+    n = 300
+    v = oracle.OracleVec(oracle.PONG, n, seed=SEED)
+    v.reset()
+    env = np.arange(n, dtype=np.uint64)
+    bx, by, vx, vy = NP.pong_reset_ball(SEED, env, 0, 0)
+    st = np.stack([bx, by, vx, vy, np.full(n, 97.5), np.full(n, 97.5)])
+    ints = np.zeros((3, n), np.int32)
+    reals, i0 = v.get_state()
+    assert np.array_equal(bits(reals), bits(st)) and np.array_equal(i0, ints)
+    rng = np.random.default_rng(4)
+    for t in range(400):
+        a = rng.integers(0, 4, n).astype(np.int32)
+        rew, done, _ = v.step(a)
+        st, ints, rew2, done2 = NP.pong_step(st, ints, a, SEED, env, t + 1)
+        reals, i0 = v.get_state()
+        assert np.array_equal(bits(reals), bits(st)), t
+        assert np.array_equal(i0, ints) and np.array_equal(rew, rew2) and np.array_equal(done.astype(bool), done2)
+    assert ints[:2].sum() > 0  # some points were scored, so ResetBall was exercised
+    frames = v.get_obs()
+    for i in range(0, n, 37):
+        exp = NP.pong_frame(st[0, i], st[1, i], st[4, i], st[5, i], ints[0, i], ints[1, i])
+        assert np.array_equal(frames[i], exp)
+
+
+def test_pong_frames_edge_cases(oracle):
+    cases = [
+        (160.0, 208.0, 0.0, 195.0, 21, 9), (0.0, 0.0, 195.0, 0.0, 10, 123), (159.2, 104.9, 3.2, 190.8, 0, 21),
+        (79.5, 19.5, 97.5, 97.5, 7, 8), (38.0, 21.0, 50.0, 60.0, 4, 1234567),
+    ]
+    for c in cases:
+        assert np.array_equal(oracle.pong_render(*c), NP.pong_frame(*c)), c
+
+
+def test_wrappers_match_numpy_restatement(oracle):
+    """RecordEpisodeStatistics(TimeLimit(CartPole)) without autoreset, stepping past done."""
+    n = 64
+    v = oracle.OracleVec(oracle.CARTPOLE, n, seed=9, flags=oracle.RECORD_STATS, time_limit=25)
+    v.reset()
+    res = [NP.RecordEpisodeStatistics() for _ in range(n)]
+    tls = [NP.TimeLimit(25) for _ in range(n)]
+    s = NP.cartpole_reset(9, np.arange(n, dtype=np.uint64), 0); st = np.zeros(n, np.int32)
+    rng = np.random.default_rng(5)
+    for t in range(60):
+        if t == 40:
+            v.reset()
+            for r_, tl in zip(res, tls):
+                r_.reset(); tl.reset()
+            s = NP.cartpole_reset(9, np.arange(n, dtype=np.uint64), v.tick - 1); st = np.zeros(n, np.int32)
+        a = rng.integers(0, 2, n).astype(np.int32)
+        rew, done, trunc = v.step(a)
+        s, st, rew2, done2 = NP.cartpole_step(s, st, a)
+        for i in range(n):
+            d, tr = tls[i].step(done2[i])
+            res[i].step(float(rew2[i]), d)
+            assert d == bool(done[i]) and tr == bool(trunc[i])
+    for i in range(n):
+        assert v.episodes(i) == list(zip(res[i].episode_rewards, res[i].episode_lengths))
