@@ -1,0 +1,112 @@
+"""ctypes binding of libgymx.so (include/gymx.h).
+
+The library is the product: if it cannot be loaded this module raises, there
+is no Python or CPU fallback behind it.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgymx.so")
+
+GX_OK, GX_ERR_INVALID, GX_ERR_HIP, GX_ERR_OOM, GX_ERR_UNSUPPORTED, GX_ERR_RCCL = range(6)
+
+(ENV_CARTPOLE, ENV_MOUNTAINCAR, ENV_MOUNTAINCAR_CONT, ENV_PENDULUM, ENV_ACROBOT, ENV_FROZENLAKE, ENV_TAXI,
+ ENV_CLIFFWALKING, ENV_PONG, ENV_DUMMY) = range(10)
+MODE_EXACT, MODE_FAST32 = 0, 1
+AUTORESET, RECORD_STATS, SLIPPERY, TAXI_FULL, ACROBOT_RK4 = 1, 2, 4, 8, 16
+POLICY_DEVICE_ACTIONS, POLICY_RANDOM = 0, 1
+F32, F64, I32, U8 = range(4)
+
+
+class GxDesc(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("env_id", C.c_int32), ("num_envs", C.c_uint64), ("seed", C.c_uint64),
+        ("env_index_base", C.c_uint64), ("mode", C.c_int32), ("flags", C.c_uint32), ("time_limit", C.c_int32),
+        ("reserved", C.c_int32), ("map_rows", C.c_char_p),
+    ]
+
+
+class GxInfo(C.Structure):
+    _fields_ = [
+        ("num_envs", C.c_uint64), ("env_id", C.c_int32), ("n_real", C.c_int32), ("real_dtype", C.c_int32),
+        ("n_int", C.c_int32), ("obs_dim", C.c_int32), ("obs_dtype", C.c_int32), ("action_dtype", C.c_int32),
+        ("action_n", C.c_int32), ("action_low", C.c_float), ("action_high", C.c_float), ("reward_dtype", C.c_int32),
+        ("obs_is_state", C.c_int32), ("state_bytes", C.c_uint64), ("obs_bytes", C.c_uint64),
+    ]
+
+
+class GxView(C.Structure):
+    _fields_ = [
+        ("num_envs", C.c_uint64), ("stride", C.c_uint64), ("state_real", C.c_void_p), ("state_int", C.c_void_p),
+        ("obs", C.c_void_p), ("reward", C.c_void_p), ("done", C.c_void_p), ("truncated", C.c_void_p),
+    ]
+
+
+class GxStats(C.Structure):
+    _fields_ = [
+        ("episodes", C.c_int64), ("sum_return", C.c_double), ("sum_length", C.c_int64),
+        ("sum_return_sq", C.c_double), ("min_return", C.c_double), ("max_return", C.c_double),
+    ]
+
+
+class GymxError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("gymx error %d: %s" % (code, message))
+        self.code = code
+
+
+# Every symbol include/gymx.h declares, with its signature.
+_vp, _u64, _i = C.c_void_p, C.c_uint64, C.c_int
+SIGNATURES = {
+    "gx_version": (C.c_uint32, []),
+    "gx_last_error": (C.c_char_p, []),
+    "gx_device_count": (_i, [C.POINTER(_i)]),
+    "gx_ctx_create": (_i, [_i, C.POINTER(_vp)]),
+    "gx_ctx_destroy": (_i, [_vp]),
+    "gx_ctx_synchronize": (_i, [_vp]),
+    "gx_ctx_stream": (_i, [_vp, C.POINTER(_vp)]),
+    "gx_vec_create": (_i, [_vp, C.POINTER(GxDesc), C.POINTER(_vp)]),
+    "gx_vec_destroy": (_i, [_vp]),
+    "gx_vec_info": (_i, [_vp, C.POINTER(GxInfo)]),
+    "gx_vec_reset": (_i, [_vp]),
+    "gx_vec_get_state": (_i, [_vp, _vp, C.c_size_t]),
+    "gx_vec_set_state": (_i, [_vp, _vp, C.c_size_t]),
+    "gx_vec_get_obs": (_i, [_vp, _vp, C.c_size_t]),
+    "gx_vec_step_async": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "gx_vec_wait": (_i, [_vp]),
+    "gx_vec_step_device": (_i, [_vp, _vp, _vp]),
+    "gx_vec_step_random": (_i, [_vp, _vp]),
+    "gx_vec_device_view": (_i, [_vp, C.POINTER(GxView)]),
+    "gx_vec_rollout": (_i, [_vp, _i, _i, _vp, _vp]),
+    "gx_vec_sample_actions": (_i, [_vp, _u64, _vp, _vp]),
+    "gx_vec_tick": (_i, [_vp, C.POINTER(_u64)]),
+    "gx_vec_stats": (_i, [_vp, C.POINTER(GxStats)]),
+    "gx_comm_unique_id": (_i, [_vp]),
+    "gx_comm_init": (_i, [_vp, _vp, _i, _i, C.POINTER(_vp)]),
+    "gx_comm_destroy": (_i, [_vp]),
+    "gx_stats_allreduce": (_i, [_vp, _vp, C.POINTER(GxStats)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libgymx.so; raises ImportError with the build hint when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: run `python -m gym_amd.build` (needs hipcc); there is no fallback path" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code):
+    if code != GX_OK:
+        raise GymxError(code, load().gx_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,61 @@
+"""Builds libgymx.so (the HIP kernels and the C ABI) for gfx950, in-tree.
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the
+resulting gym_amd/lib/libgymx.so travels to the GPU box with the source tree.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "lib", "obj")
+LIB = os.path.join(HERE, "lib", "libgymx.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+SOURCES = ["gx_api.cpp", "gx_classic.hip", "gx_acrobot64.hip", "gx_tabular.hip", "gx_pong.hip", "gx_stats.hip"]
+# -ffp-contract=off: EXACT mode is operation-for-operation binary32; fused
+# multiply-adds are written out explicitly where they are wanted.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function"]
+
+
+def _deps():
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs.append(os.path.join(os.path.dirname(HERE), "include", "gymx.h"))
+    return max(os.path.getmtime(h) for h in hdrs)
+
+
+def _compile(src):
+    s = os.path.join(CSRC, src)
+    o = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+    if os.path.exists(o) and os.path.getmtime(o) >= max(os.path.getmtime(s), _deps()):
+        return o, False
+    cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", s, "-o", o]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed on %s:\n%s" % (src, r.stderr[-4000:]))
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr[-2000:])
+    return o, True
+
+
+def build(force=False):
+    os.makedirs(OBJ, exist_ok=True)
+    if force:
+        for f in os.listdir(OBJ):
+            os.remove(os.path.join(OBJ, f))
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        results = list(ex.map(_compile, SOURCES))
+    objs = [o for o, _ in results]
+    if any(changed for _, changed in results) or not os.path.exists(LIB):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s" % r.stderr[-4000:])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

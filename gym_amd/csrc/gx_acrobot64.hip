@@ -1,0 +1,126 @@
+// Acrobot with the upstream dynamics: classical RK4 in binary64.
+//
+// EXTENSION -- the reference integrates Acrobot with semi-implicit Euler in
+// binary32 (Envs.Acrobot.cs:69-74); this variant follows the published
+// Gymnasium "book" equations with the reference's constants
+// (Envs.Acrobot.cs:33-44): state (theta1, theta2, dtheta1, dtheta2) in double,
+// one RK4 step of dt = 0.2, both angles wrapped to [-pi, pi], velocity bounds
+// 4pi / 9pi, terminal when -cos(t1) - cos(t1 + t2) > 1 or after 500 steps.
+// It is the FP64 vector-ALU workload: in a K-step rollout the state never
+// leaves registers.  Two envs per lane (16 bytes of each double row).
+//
+// Every a*b+c is an explicit fma() (and nothing else is contracted) so that a
+// CPU restatement written with the same fma() calls can match wherever the
+// sin/cos results agree.
+#pragma clang fp contract(off)
+
+#include "gx_classic_kernel.h"
+
+namespace gx {
+
+struct Acrobot64 {
+  static constexpr int NS = 4;
+  using Real = double;
+  static constexpr int W = 2;
+  static constexpr bool kDerivedObs = true;
+  static constexpr int NOBS = 6;
+  using Act = int32_t;
+  using Rew = float;
+  using EpRet = int32_t;
+  static constexpr int NACT = 3;
+  static constexpr bool kCheckAction = true;
+  static __device__ __forceinline__ bool action_valid(Act a) { return (uint32_t)a <= 2u; }
+
+  static __device__ __forceinline__ void reset(double (&s)[NS], const RngKey& key, uint64_t env) {
+    Draws d0 = philox_block(key, env, 0, 0), d1 = philox_block(key, env, 0, 1);
+    s[0] = fma(d0.uniform(0), 0.2, -0.1);
+    s[1] = fma(d0.uniform(1), 0.2, -0.1);
+    s[2] = fma(d1.uniform(0), 0.2, -0.1);
+    s[3] = fma(d1.uniform(1), 0.2, -0.1);
+  }
+
+  static __device__ __forceinline__ void dsdt(const double (&y)[4], double u, double (&dy)[4]) {
+    const double g = 9.8;
+    const double t1 = y[0], t2 = y[1], w1 = y[2], w2 = y[3];
+    double s2, c2;
+    ::sincos(t2, &s2, &c2);
+    const double d1 = c2 + 3.5;
+    const double d2 = fma(0.5, c2, 1.25);
+    const double phi2 = (0.5 * g) * ::cos(t1 + t2 - M_PI / 2.0);
+    double phi1 = fma(1.5 * g, ::cos(t1 - M_PI / 2.0), phi2);
+    phi1 = fma(-(w2 * s2), w1, phi1);
+    phi1 = fma(-0.5 * (w2 * s2), w2, phi1);
+    const double r = d2 / d1;
+    double num = fma(r, phi1, u);
+    num = fma(-0.5 * (w1 * s2), w1, num) - phi2;
+    const double den = fma(-d2, r, 1.25);
+    const double a2 = num / den;
+    const double a1 = -fma(d2, a2, phi1) / d1;
+    dy[0] = w1; dy[1] = w2; dy[2] = a1; dy[3] = a2;
+  }
+
+  static __device__ __forceinline__ double wrap_pi(double x) {
+    const double two_pi = 2.0 * M_PI;
+    while (x > M_PI) x -= two_pi;
+    while (x < -M_PI) x += two_pi;
+    return x;
+  }
+
+  template <int MODE>
+  static __device__ __forceinline__ void step(double (&s)[NS], int32_t& steps, Act action, Rew& reward, bool& done) {
+    const double dt = 0.2;
+    const double u = action == 0 ? -1.0 : (action == 2 ? 1.0 : 0.0);
+    double k1[4], k2[4], k3[4], k4[4], y[4];
+    dsdt(s, u, k1);
+#pragma unroll
+    for (int i = 0; i < 4; i++) y[i] = fma(0.5 * dt, k1[i], s[i]);
+    dsdt(y, u, k2);
+#pragma unroll
+    for (int i = 0; i < 4; i++) y[i] = fma(0.5 * dt, k2[i], s[i]);
+    dsdt(y, u, k3);
+#pragma unroll
+    for (int i = 0; i < 4; i++) y[i] = fma(dt, k3[i], s[i]);
+    dsdt(y, u, k4);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      double sum = fma(2.0, k2[i], k1[i]);
+      sum = fma(2.0, k3[i], sum) + k4[i];
+      y[i] = fma(dt / 6.0, sum, s[i]);
+    }
+    y[0] = wrap_pi(y[0]);
+    y[1] = wrap_pi(y[1]);
+    const double mv1 = 4.0 * M_PI, mv2 = 9.0 * M_PI;
+    y[2] = y[2] < -mv1 ? -mv1 : (y[2] > mv1 ? mv1 : y[2]);
+    y[3] = y[3] < -mv2 ? -mv2 : (y[3] > mv2 ? mv2 : y[3]);
+#pragma unroll
+    for (int i = 0; i < 4; i++) s[i] = y[i];
+    steps++;
+    done = (-::cos(y[0]) - ::cos(y[1] + y[0]) > 1.0) || steps >= 500;
+    reward = done ? 0.0f : -1.0f;
+  }
+
+  // the reference's observation layout (Envs.Acrobot.cs:77-82)
+  static __device__ __forceinline__ void observe(const double (&s)[NS], float (&o)[NOBS]) {
+    double sn, cs;
+    ::sincos(s[0], &sn, &cs);
+    o[0] = (float)cs; o[1] = (float)sn;
+    ::sincos(s[1], &sn, &cs);
+    o[2] = (float)cs; o[3] = (float)sn;
+    o[4] = (float)s[2];
+    o[5] = (float)s[3];
+  }
+
+  static __device__ __forceinline__ Act sample(const Draws& d) { return d.below(0, NACT); }
+};
+
+hipError_t launch_acrobot64_step(const StepArgs& a, int policy, dim3 grid, hipStream_t stream) {
+  return launch_step_env<Acrobot64>(a, GX_MODE_EXACT, policy, grid, stream);
+}
+hipError_t launch_acrobot64_reset(const StepArgs& a, int only_observe, dim3 grid, hipStream_t stream) {
+  return launch_reset_env<Acrobot64>(a, only_observe, grid, stream);
+}
+hipError_t launch_acrobot64_sample(const StepArgs& a, void* out, dim3 grid, hipStream_t stream) {
+  return launch_sample_env<Acrobot64>(a, out, grid, stream);
+}
+
+}  // namespace gx

@@ -1,0 +1,891 @@
+// C ABI of libgymx.so (include/gymx.h): contexts, batches, host and zero-copy
+// step paths, state get/set, statistics and the RCCL statistics all-reduce.
+//
+// There is no CPU implementation behind this file: every entry point that
+// computes launches a gfx950 kernel, and fails with GX_ERR_HIP when no device
+// is present.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/gymx.h"
+#include "gx_device.h"
+#include "gx_launch.h"
+
+using namespace gx;
+
+// ------------------------------------------------------------------ errors ---
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      return fail(e_ == hipErrorOutOfMemory ? GX_ERR_OOM : GX_ERR_HIP, "%s failed: %s", #expr, \
+                  hipGetErrorString(e_));                                                     \
+  } while (0)
+
+// ----------------------------------------------------------------- handles ---
+struct gx_ctx {
+  int device = 0;
+  int num_cus = 0;
+  hipStream_t compute = nullptr;
+  hipStream_t copy = nullptr;
+  hipEvent_t ev_in = nullptr;
+  hipEvent_t ev_out = nullptr;
+};
+
+struct gx_vec {
+  gx_ctx* ctx = nullptr;
+  gx_desc desc{};
+  gx_info info{};
+  std::string map;
+  uint64_t n = 0, stride = 0, tick = 0;
+  int envs_per_lane = 4;
+  bool is_classic = false, is_tabular = false, is_pong = false, is_acrobot64 = false;
+  bool ep_return_f64 = false;
+  // device memory
+  void* d_real = nullptr;
+  int32_t* d_int = nullptr;
+  void* d_reward = nullptr;
+  uint8_t* d_done = nullptr;
+  uint8_t* d_trunc = nullptr;
+  void* d_ep_return = nullptr;
+  int32_t* d_ep_length = nullptr;
+  StatSlot* d_slots = nullptr;  // [num_slots] + 1 result slot
+  int num_slots = 0;
+  float* d_obs = nullptr;
+  uint8_t* d_frames = nullptr;
+  uint32_t* d_table = nullptr;
+  uint32_t* d_error = nullptr;
+  void* d_actions = nullptr;  // staging for the host path
+  uint32_t* h_error = nullptr;  // pinned
+  StatSlot* h_stat = nullptr;   // pinned
+  bool frames_valid = false;
+  // tabular
+  int table_states = 0, table_actions = 0, table_outcomes = 1, start_state = 0, step_limit = 0;
+  size_t table_lds_bytes = 0;
+  dim3 grid;
+};
+
+struct gx_comm {
+  gx_ctx* ctx = nullptr;
+  void* lib = nullptr;
+  void* comm = nullptr;
+  double* d_buf = nullptr;
+  double* h_buf = nullptr;
+  int rank = 0, world = 1;
+};
+
+static size_t dtype_size(int dt) { return dt == GX_F64 ? 8 : (dt == GX_U8 ? 1 : 4); }
+
+// ------------------------------------------------------------------ library ---
+extern "C" uint32_t gx_version(void) { return GX_VERSION; }
+extern "C" const char* gx_last_error(void) { return g_err; }
+
+extern "C" int gx_device_count(int* count) {
+  if (!count) return fail(GX_ERR_INVALID, "gx_device_count: null argument");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(GX_ERR_HIP, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+  }
+  *count = n;
+  return GX_OK;
+}
+
+// ------------------------------------------------------------------ context ---
+extern "C" int gx_ctx_create(int device, gx_ctx** out) {
+  if (!out) return fail(GX_ERR_INVALID, "gx_ctx_create: null out pointer");
+  *out = nullptr;
+  int n = 0;
+  HIP_TRY(hipGetDeviceCount(&n));
+  if (device < 0 || device >= n) return fail(GX_ERR_INVALID, "gx_ctx_create: device %d of %d", device, n);
+  HIP_TRY(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(GX_ERR_UNSUPPORTED, "gx_ctx_create: device %d is %s; this library is built for gfx950 only", device,
+                prop.gcnArchName);
+  gx_ctx* c = new (std::nothrow) gx_ctx();
+  if (!c) return fail(GX_ERR_OOM, "gx_ctx_create: host allocation failed");
+  c->device = device;
+  c->num_cus = prop.multiProcessorCount;
+  hipError_t e = hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming);
+  if (e != hipSuccess) {
+    gx_ctx_destroy(c);
+    return fail(GX_ERR_HIP, "gx_ctx_create: stream/event creation failed: %s", hipGetErrorString(e));
+  }
+  *out = c;
+  return GX_OK;
+}
+
+extern "C" int gx_ctx_destroy(gx_ctx* c) {
+  if (!c) return GX_OK;
+  (void)hipSetDevice(c->device);
+  if (c->ev_in) (void)hipEventDestroy(c->ev_in);
+  if (c->ev_out) (void)hipEventDestroy(c->ev_out);
+  if (c->compute) (void)hipStreamDestroy(c->compute);
+  if (c->copy) (void)hipStreamDestroy(c->copy);
+  delete c;
+  return GX_OK;
+}
+
+extern "C" int gx_ctx_synchronize(gx_ctx* c) {
+  if (!c) return fail(GX_ERR_INVALID, "gx_ctx_synchronize: null context");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->compute));
+  HIP_TRY(hipStreamSynchronize(c->copy));
+  return GX_OK;
+}
+
+extern "C" int gx_ctx_stream(gx_ctx* c, void** stream) {
+  if (!c || !stream) return fail(GX_ERR_INVALID, "gx_ctx_stream: null argument");
+  *stream = c->compute;
+  return GX_OK;
+}
+
+// ------------------------------------------------- tabular table compilation ---
+// Packs an env into entry[(s * (A + 1) + col) * O + o] followed by 8 rewards.
+namespace {
+
+constexpr uint32_t kTerminalBit = 1u << 24;
+const char* const kFrozenLake4x4 = "SFFF/FHFH/FFFH/HFFG";  // Envs.FrozenLake.cs:25-30
+const char* const kFrozenLake8x8 = "SFFFFFFF/FFFFFFFF/FFFHFFFF/FFFFFHFF/FFFHFFFF/FHHFFFHF/FHFFHFHF/FFFHFFFG";
+
+struct Grid {
+  int nrow = 0, ncol = 0, goal = -1;
+  std::vector<uint8_t> hole;
+};
+
+// Envs.FrozenLake.cs:31-42
+int parse_map(const std::string& rows, Grid& g) {
+  std::vector<std::string> lines;
+  std::string cur;
+  for (char ch : rows) {
+    if (ch == '/' || ch == '\n') {
+      if (!cur.empty()) lines.push_back(cur);
+      cur.clear();
+    } else {
+      cur.push_back(ch);
+    }
+  }
+  if (!cur.empty()) lines.push_back(cur);
+  if (lines.empty()) return -1;
+  g.nrow = (int)lines.size();
+  g.ncol = (int)lines[0].size();
+  if ((long long)g.nrow * g.ncol > 4096) return -1;
+  g.hole.assign((size_t)g.nrow * g.ncol, 0);
+  g.goal = -1;
+  for (int r = 0; r < g.nrow; r++) {
+    if ((int)lines[r].size() != g.ncol) return -1;
+    for (int c = 0; c < g.ncol; c++) {
+      if (lines[r][c] == 'G') g.goal = r * g.ncol + c;
+      if (lines[r][c] == 'H') g.hole[(size_t)r * g.ncol + c] = 1;
+    }
+  }
+  return 0;
+}
+
+// Envs.FrozenLake.cs:54-63 / Envs.CliffWalking.cs:38-47
+int grid_move(const Grid& g, int s, int a) {
+  int row = s / g.ncol, col = s % g.ncol;
+  switch (a) {
+    case 0: col = col - 1 > 0 ? col - 1 : 0; break;
+    case 1: row = row + 1 < g.nrow - 1 ? row + 1 : g.nrow - 1; break;
+    case 2: col = col + 1 < g.ncol - 1 ? col + 1 : g.ncol - 1; break;
+    case 3: row = row - 1 > 0 ? row - 1 : 0; break;
+    default: break;
+  }
+  return row * g.ncol + col;
+}
+
+// upstream Taxi-v3 transition (extension; the reference's Taxi is a stub)
+void taxi_full(int s, int a, int& ns, int& ridx, bool& term) {
+  static const int loc_r[4] = {0, 0, 4, 4}, loc_c[4] = {0, 4, 0, 3};
+  static const uint8_t wall_e[5][5] = {
+      {0, 1, 0, 0, 1}, {0, 1, 0, 0, 1}, {0, 0, 0, 0, 1}, {1, 0, 1, 0, 1}, {1, 0, 1, 0, 1}};
+  int dest = s % 4, pass = (s / 4) % 5, col = (s / 20) % 5, row = s / 100;
+  ridx = 0;  // -1
+  term = false;
+  switch (a) {
+    case 0: row = row + 1 < 4 ? row + 1 : 4; break;
+    case 1: row = row - 1 > 0 ? row - 1 : 0; break;
+    case 2: if (!wall_e[row][col]) col += 1; break;
+    case 3: if (col > 0 && !wall_e[row][col - 1]) col -= 1; break;
+    case 4:
+      if (pass < 4 && row == loc_r[pass] && col == loc_c[pass]) pass = 4;
+      else ridx = 1;  // -10
+      break;
+    case 5: {
+      int at = -1;
+      for (int k = 0; k < 4; k++)
+        if (row == loc_r[k] && col == loc_c[k]) at = k;
+      if (pass == 4 && at == dest) { pass = dest; ridx = 2; term = true; }  // +20
+      else if (pass == 4 && at >= 0) pass = at;
+      else ridx = 1;
+      break;
+    }
+    default: break;
+  }
+  ns = ((row * 5 + col) * 5 + pass) * 4 + dest;
+}
+
+int build_table(gx_vec* v, std::vector<uint32_t>& tab) {
+  const int env = v->desc.env_id;
+  float lut[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (env == GX_ENV_FROZENLAKE || env == GX_ENV_CLIFFWALKING) {
+    Grid g;
+    const bool cliff = env == GX_ENV_CLIFFWALKING;
+    if (cliff) {
+      // Envs.CliffWalking.cs:15-27
+      g.nrow = 4; g.ncol = 12; g.goal = 47;
+      g.hole.assign(48, 0);
+      for (int c = 1; c < 11; c++) g.hole[36 + c] = 1;
+      v->start_state = 36;
+      lut[0] = -1.0f; lut[1] = -100.0f; lut[2] = 0.0f;  // Envs.CliffWalking.cs:50-51
+    } else {
+      std::string rows = v->map.empty() ? kFrozenLake4x4 : (v->map == "8x8" ? kFrozenLake8x8 : v->map);
+      if (parse_map(rows, g) != 0) return fail(GX_ERR_INVALID, "gx_vec_create: malformed FrozenLake map");
+      v->start_state = 0;
+      lut[0] = 0.0f; lut[1] = 1.0f;  // Envs.FrozenLake.cs:66
+    }
+    const int S = g.nrow * g.ncol, A = 4;
+    const int O = (!cliff && (v->desc.flags & GX_SLIPPERY)) ? 3 : 1;
+    v->table_states = S; v->table_actions = A; v->table_outcomes = O;
+    v->step_limit = 100;  // Envs.FrozenLake.cs:65, Envs.CliffWalking.cs:49
+    v->info.obs_dim = 1;
+    tab.assign((size_t)S * (A + 1) * O + 8, 0);
+    for (int s = 0; s < S; s++)
+      for (int col = 0; col <= A; col++)
+        for (int o = 0; o < O; o++) {
+          // slippery: the executed action is a-1, a or a+1 (mod 4)
+          int a = col < A ? (O == 3 ? ((col + 3 + o) & 3) : col) : -1;
+          int ns = grid_move(g, s, a);
+          const bool goal = ns == g.goal, hole = g.hole[(size_t)ns] != 0;
+          uint32_t ridx = cliff ? (goal ? 2u : (hole ? 1u : 0u)) : (goal ? 1u : 0u);
+          tab[((size_t)s * (A + 1) + col) * O + o] = (uint32_t)ns | (ridx << 16) | ((goal || hole) ? kTerminalBit : 0u);
+        }
+  } else if (env == GX_ENV_TAXI) {
+    const int S = 500, A = 6;
+    const bool full = (v->desc.flags & GX_TAXI_FULL) != 0;
+    v->table_states = S; v->table_actions = A; v->table_outcomes = 1;
+    v->step_limit = 200;  // Envs.Taxi.cs:29
+    v->start_state = full ? -2 : -1;
+    lut[0] = -1.0f; lut[1] = -10.0f; lut[2] = 20.0f;  // Envs.Taxi.cs:30 uses -1 only
+    tab.assign((size_t)S * (A + 1) + 8, 0);
+    for (int s = 0; s < S; s++)
+      for (int col = 0; col <= A; col++) {
+        int ns = s, ridx = 0;
+        bool term = false;
+        if (full) taxi_full(s, col < A ? col : -1, ns, ridx, term);
+        tab[(size_t)s * (A + 1) + col] = (uint32_t)ns | ((uint32_t)ridx << 16) | (term ? kTerminalBit : 0u);
+      }
+  } else {
+    return GX_OK;
+  }
+  std::memcpy(&tab[tab.size() - 8], lut, sizeof lut);
+  return GX_OK;
+}
+
+void fill_info(gx_vec* v) {
+  gx_info& in = v->info;
+  const int env = v->desc.env_id;
+  in.num_envs = v->n;
+  in.env_id = env;
+  in.real_dtype = GX_F32;
+  in.obs_dtype = GX_F32;
+  in.action_dtype = GX_I32;
+  in.reward_dtype = GX_F32;
+  in.obs_is_state = 1;
+  in.action_low = in.action_high = 0.0f;
+  switch (env) {
+    case GX_ENV_CARTPOLE: in.n_real = 4; in.n_int = 1; in.obs_dim = 4; in.action_n = 2; break;   // Envs.CartPole.cs:12-16
+    case GX_ENV_MOUNTAINCAR: in.n_real = 2; in.n_int = 1; in.obs_dim = 2; in.action_n = 3; break; // Envs.MountainCar.cs:12-16
+    case GX_ENV_MOUNTAINCAR_CONT:                                                                 // Envs.MountainCarContinuous.cs:12-13
+      in.n_real = 2; in.n_int = 1; in.obs_dim = 2; in.action_n = 0; in.action_dtype = GX_F32;
+      in.action_low = -1.0f; in.action_high = 1.0f; in.reward_dtype = GX_F64;
+      break;
+    case GX_ENV_PENDULUM:                                                                         // Envs.Pendulum.cs:12-13
+      in.n_real = 3; in.n_int = 1; in.obs_dim = 3; in.action_n = 0; in.action_dtype = GX_F32;
+      in.action_low = -2.0f; in.action_high = 2.0f; in.reward_dtype = GX_F64;
+      break;
+    case GX_ENV_ACROBOT:                                                                          // Envs.Acrobot.cs:12-16
+      in.obs_dim = 6; in.action_n = 3; in.n_int = 1;
+      if (v->is_acrobot64) { in.n_real = 4; in.real_dtype = GX_F64; in.obs_is_state = 0; }
+      else in.n_real = 6;
+      break;
+    case GX_ENV_FROZENLAKE: in.n_real = 0; in.n_int = 2; in.obs_dim = 1; in.obs_dtype = GX_I32; in.action_n = 4; break;
+    case GX_ENV_TAXI: in.n_real = 0; in.n_int = 2; in.obs_dim = 1; in.obs_dtype = GX_I32; in.action_n = 6; break;
+    case GX_ENV_CLIFFWALKING: in.n_real = 0; in.n_int = 2; in.obs_dim = 1; in.obs_dtype = GX_I32; in.action_n = 4; break;
+    case GX_ENV_DUMMY: in.n_real = 0; in.n_int = 2; in.obs_dim = 1; in.obs_dtype = GX_I32; in.action_n = 3; break;
+    case GX_ENV_PONG:                                                                             // Envs.Pong.cs:36-41
+      in.n_real = 6; in.real_dtype = GX_F64; in.n_int = 3; in.obs_dim = 210 * 160 * 3; in.obs_dtype = GX_U8;
+      in.action_n = 4; in.obs_is_state = 0;
+      break;
+  }
+  in.state_bytes = v->n * ((uint64_t)in.n_real * dtype_size(in.real_dtype) + (uint64_t)in.n_int * 4);
+  in.obs_bytes = v->n * (uint64_t)in.obs_dim * dtype_size(in.obs_dtype);
+}
+
+StepArgs make_args(const gx_vec* v, const void* d_actions, int k_steps, uint64_t action_stride) {
+  StepArgs a{};
+  a.state_real = v->d_real;
+  a.state_int = v->d_int;
+  a.actions = d_actions;
+  a.reward = v->d_reward;
+  a.done = v->d_done;
+  a.truncated = v->d_trunc;
+  a.ep_return = v->d_ep_return;
+  a.ep_length = v->d_ep_length;
+  a.stat_slots = v->d_slots;
+  a.obs = v->d_obs;
+  a.table = v->d_table;
+  a.error_flag = v->d_error;
+  a.num_envs = v->n;
+  a.stride = v->stride;
+  a.action_stride = action_stride;
+  a.env_index_base = v->desc.env_index_base;
+  a.tick = v->tick;
+  a.seed_lo = (uint32_t)v->desc.seed;
+  a.seed_hi = (uint32_t)(v->desc.seed >> 32);
+  a.flags = v->desc.flags;
+  a.time_limit = v->desc.time_limit;
+  a.k_steps = k_steps;
+  a.table_states = v->table_states;
+  a.table_actions = v->table_actions;
+  a.table_outcomes = v->table_outcomes;
+  a.start_state = v->start_state;
+  a.step_limit = v->step_limit;
+  return a;
+}
+
+int launch_step(gx_vec* v, const void* d_actions, int k_steps, uint64_t action_stride, int policy, hipStream_t stream) {
+  StepArgs a = make_args(v, d_actions, k_steps, action_stride);
+  hipError_t e;
+  if (v->is_acrobot64) e = launch_acrobot64_step(a, policy, v->grid, stream);
+  else if (v->is_classic) e = launch_classic_step(v->desc.env_id, a, v->desc.mode, policy, v->grid, stream);
+  else if (v->is_tabular) e = launch_tabular_step(v->desc.env_id, a, policy, v->grid, v->table_lds_bytes, stream);
+  else {
+    e = launch_pong_step(a, policy, v->grid, stream);
+    if (e == hipSuccess) e = launch_pong_raster(a, v->d_frames, stream);
+    v->frames_valid = true;
+  }
+  if (e != hipSuccess) return fail(GX_ERR_HIP, "step kernel launch failed: %s", hipGetErrorString(e));
+  v->tick += (uint64_t)k_steps;
+  return GX_OK;
+}
+
+int launch_sample(gx_vec* v, uint64_t tick, void* d_out, hipStream_t stream) {
+  StepArgs a = make_args(v, nullptr, 1, 0);
+  a.tick = tick;
+  uint64_t blocks = (v->n + kBlock - 1) / kBlock;
+  dim3 grid((unsigned)std::min<uint64_t>(blocks ? blocks : 1, (uint64_t)v->ctx->num_cus * 8));
+  hipError_t e;
+  if (v->is_acrobot64) e = launch_acrobot64_sample(a, d_out, grid, stream);
+  else if (v->is_classic) e = launch_classic_sample(v->desc.env_id, a, d_out, grid, stream);
+  else if (v->is_tabular) e = launch_tabular_sample(v->desc.env_id, a, d_out, grid, stream);
+  else e = launch_pong_sample(a, d_out, grid, stream);
+  if (e != hipSuccess) return fail(GX_ERR_HIP, "sample kernel launch failed: %s", hipGetErrorString(e));
+  return GX_OK;
+}
+
+// copy `rows` SoA rows of `n` elements between a packed host image and the
+// strided device image
+int copy_rows(void* dst, const void* src, size_t elem, int rows, uint64_t n, uint64_t dst_stride, uint64_t src_stride,
+              hipMemcpyKind kind, hipStream_t stream) {
+  if (rows == 0 || n == 0) return GX_OK;
+  HIP_TRY(hipMemcpy2DAsync(dst, dst_stride * elem, src, src_stride * elem, n * elem, (size_t)rows, kind, stream));
+  return GX_OK;
+}
+
+}  // namespace
+
+// -------------------------------------------------------------------- batch ---
+extern "C" int gx_vec_destroy(gx_vec* v) {
+  if (!v) return GX_OK;
+  if (v->ctx) {
+    (void)hipSetDevice(v->ctx->device);
+    (void)hipStreamSynchronize(v->ctx->compute);
+    (void)hipStreamSynchronize(v->ctx->copy);
+  }
+  void* dev[] = {v->d_real, v->d_int, v->d_reward, v->d_done, v->d_trunc, v->d_ep_return, v->d_ep_length,
+                 v->d_slots, v->d_obs, v->d_frames, v->d_table, v->d_error, v->d_actions};
+  for (void* p : dev)
+    if (p) (void)hipFree(p);
+  if (v->h_error) (void)hipHostFree(v->h_error);
+  if (v->h_stat) (void)hipHostFree(v->h_stat);
+  delete v;
+  return GX_OK;
+}
+
+extern "C" int gx_vec_create(gx_ctx* ctx, const gx_desc* desc, gx_vec** out) {
+  if (!ctx || !desc || !out) return fail(GX_ERR_INVALID, "gx_vec_create: null argument");
+  *out = nullptr;
+  if (desc->struct_size != sizeof(gx_desc))
+    return fail(GX_ERR_INVALID, "gx_vec_create: gx_desc.struct_size is %u, expected %zu", desc->struct_size, sizeof(gx_desc));
+  if (desc->env_id < 0 || desc->env_id >= GX_ENV_COUNT) return fail(GX_ERR_INVALID, "gx_vec_create: unknown env id %d", desc->env_id);
+  if (desc->num_envs == 0) return fail(GX_ERR_INVALID, "gx_vec_create: num_envs must be positive");
+  if (desc->num_envs > (1ull << 31)) return fail(GX_ERR_UNSUPPORTED, "gx_vec_create: more than 2^31 envs per batch");
+  if (desc->mode != GX_MODE_EXACT && desc->mode != GX_MODE_FAST32) return fail(GX_ERR_INVALID, "gx_vec_create: unknown mode %d", desc->mode);
+  if (desc->time_limit < 0) return fail(GX_ERR_INVALID, "gx_vec_create: negative time_limit");
+  const uint32_t known = GX_AUTORESET | GX_RECORD_STATS | GX_SLIPPERY | GX_TAXI_FULL | GX_ACROBOT_RK4;
+  if (desc->flags & ~known) return fail(GX_ERR_INVALID, "gx_vec_create: unknown flag bits 0x%x", desc->flags & ~known);
+  HIP_TRY(hipSetDevice(ctx->device));
+
+  gx_vec* v = new (std::nothrow) gx_vec();
+  if (!v) return fail(GX_ERR_OOM, "gx_vec_create: host allocation failed");
+  v->ctx = ctx;
+  v->desc = *desc;
+  if (desc->map_rows) v->map = desc->map_rows;
+  v->desc.map_rows = nullptr;
+  v->n = desc->num_envs;
+  const int env = desc->env_id;
+  v->is_acrobot64 = env == GX_ENV_ACROBOT && (desc->flags & GX_ACROBOT_RK4);
+  v->is_classic = env <= GX_ENV_ACROBOT;
+  v->is_tabular = env == GX_ENV_FROZENLAKE || env == GX_ENV_TAXI || env == GX_ENV_CLIFFWALKING || env == GX_ENV_DUMMY;
+  v->is_pong = env == GX_ENV_PONG;
+  v->envs_per_lane = v->is_acrobot64 ? 2 : (v->is_pong ? 1 : 4);
+  v->stride = (v->n + 3) & ~3ull;  // rows stay 16-byte aligned for every element width
+  v->ep_return_f64 = env == GX_ENV_MOUNTAINCAR_CONT || env == GX_ENV_PENDULUM;
+  fill_info(v);
+
+#define VEC_TRY(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess) {                                                             \
+      gx_vec_destroy(v);                                                                \
+      return fail(e_ == hipErrorOutOfMemory ? GX_ERR_OOM : GX_ERR_HIP, "%s failed: %s", \
+                  #expr, hipGetErrorString(e_));                                        \
+    }                                                                                   \
+  } while (0)
+
+  std::vector<uint32_t> table;
+  if (v->is_tabular && env != GX_ENV_DUMMY) {
+    int rc = build_table(v, table);
+    if (rc != GX_OK) { gx_vec_destroy(v); return rc; }
+    VEC_TRY(hipMalloc((void**)&v->d_table, table.size() * 4));
+    VEC_TRY(hipMemcpy(v->d_table, table.data(), table.size() * 4, hipMemcpyHostToDevice));
+    // stage in LDS when it fits in 64 KiB, else the kernel reads the table through L2
+    v->table_lds_bytes = table.size() * 4 <= 65536 ? table.size() * 4 : 0;
+  }
+
+  const gx_info& in = v->info;
+  const size_t rsz = dtype_size(in.real_dtype);
+  if (in.n_real) VEC_TRY(hipMalloc(&v->d_real, (size_t)in.n_real * v->stride * rsz));
+  VEC_TRY(hipMalloc((void**)&v->d_int, (size_t)in.n_int * v->stride * 4));
+  VEC_TRY(hipMalloc(&v->d_reward, v->stride * dtype_size(in.reward_dtype)));
+  VEC_TRY(hipMalloc((void**)&v->d_done, v->stride));
+  if (desc->time_limit > 0) VEC_TRY(hipMalloc((void**)&v->d_trunc, v->stride));
+  VEC_TRY(hipMalloc(&v->d_actions, v->stride * 4));
+  VEC_TRY(hipMalloc((void**)&v->d_error, 256));
+  VEC_TRY(hipMemset(v->d_error, 0, 256));
+  VEC_TRY(hipHostMalloc((void**)&v->h_error, 64, hipHostMallocDefault));
+  VEC_TRY(hipHostMalloc((void**)&v->h_stat, sizeof(StatSlot), hipHostMallocDefault));
+  *v->h_error = 0;
+  if (in.n_real) VEC_TRY(hipMemset(v->d_real, 0, (size_t)in.n_real * v->stride * rsz));
+  VEC_TRY(hipMemset(v->d_int, 0, (size_t)in.n_int * v->stride * 4));
+  VEC_TRY(hipMemset(v->d_reward, 0, v->stride * dtype_size(in.reward_dtype)));
+  VEC_TRY(hipMemset(v->d_done, 0, v->stride));
+  if (v->d_trunc) VEC_TRY(hipMemset(v->d_trunc, 0, v->stride));
+  VEC_TRY(hipMemset(v->d_actions, 0, v->stride * 4));
+  if (v->is_acrobot64) VEC_TRY(hipMalloc((void**)&v->d_obs, (size_t)6 * v->stride * 4));
+  if (v->is_pong) VEC_TRY(hipMalloc((void**)&v->d_frames, v->n * (size_t)in.obs_dim));
+
+  // launch geometry: enough workgroups to fill 256 CUs eight times over, each
+  // grid-striding over lanes of `envs_per_lane` envs
+  {
+    uint64_t groups = (v->n + v->envs_per_lane - 1) / v->envs_per_lane;
+    uint64_t blocks = (groups + kBlock - 1) / kBlock;
+    uint64_t cap = (uint64_t)ctx->num_cus * 8;
+    if (const char* s = std::getenv("GYMX_GRID_BLOCKS")) {
+      long long b = std::atoll(s);
+      if (b > 0) cap = (uint64_t)b;
+    }
+    v->grid = dim3((unsigned)std::max<uint64_t>(1, std::min(blocks, cap)));
+  }
+  if (desc->flags & GX_RECORD_STATS) {
+    v->num_slots = (int)v->grid.x;
+    VEC_TRY(hipMalloc((void**)&v->d_slots, ((size_t)v->num_slots + 1) * sizeof(StatSlot)));
+    VEC_TRY(launch_stats_init(v->d_slots, v->num_slots + 1, ctx->compute));
+    const size_t esz = v->ep_return_f64 ? 8 : 4;
+    VEC_TRY(hipMalloc(&v->d_ep_return, v->stride * esz));
+    VEC_TRY(hipMemset(v->d_ep_return, 0, v->stride * esz));
+    if (!(desc->flags & GX_AUTORESET)) {
+      // without auto-reset the env's own step counter keeps running past done
+      // while RecordEpisodeStatistics restarts its length at 0
+      VEC_TRY(hipMalloc((void**)&v->d_ep_length, v->stride * 4));
+      VEC_TRY(hipMemset(v->d_ep_length, 0, v->stride * 4));
+    }
+  }
+  if (v->is_pong) {
+    // the Pong constructor calls Reset() (Envs.Pong.cs:47-52); tick stays 0
+    StepArgs a = make_args(v, nullptr, 1, 0);
+    VEC_TRY(launch_pong_reset(a, v->grid, ctx->compute));
+    VEC_TRY(launch_pong_raster(a, v->d_frames, ctx->compute));
+    v->frames_valid = true;
+  } else if (v->is_tabular && env != GX_ENV_DUMMY && env != GX_ENV_TAXI) {
+    // field initialisers: FrozenLake `_state` = 0, CliffWalking `_state` = 0 until Reset
+  }
+  if (v->is_acrobot64) {
+    StepArgs a = make_args(v, nullptr, 1, 0);
+    VEC_TRY(launch_acrobot64_reset(a, 1, v->grid, ctx->compute));
+  }
+  VEC_TRY(hipStreamSynchronize(ctx->compute));
+#undef VEC_TRY
+  *out = v;
+  return GX_OK;
+}
+
+extern "C" int gx_vec_info(const gx_vec* v, gx_info* out) {
+  if (!v || !out) return fail(GX_ERR_INVALID, "gx_vec_info: null argument");
+  *out = v->info;
+  return GX_OK;
+}
+
+extern "C" int gx_vec_tick(const gx_vec* v, uint64_t* tick) {
+  if (!v || !tick) return fail(GX_ERR_INVALID, "gx_vec_tick: null argument");
+  *tick = v->tick;
+  return GX_OK;
+}
+
+extern "C" int gx_vec_reset(gx_vec* v) {
+  if (!v) return fail(GX_ERR_INVALID, "gx_vec_reset: null batch");
+  gx_ctx* c = v->ctx;
+  HIP_TRY(hipSetDevice(c->device));
+  StepArgs a = make_args(v, nullptr, 1, 0);
+  if (v->desc.flags & GX_RECORD_STATS) {
+    // EnvWrapper.cs:34-38; with auto-reset the episode length is the step counter
+    const int32_t* len_row = v->d_ep_length ? v->d_ep_length : v->d_int + (size_t)(v->info.n_int - 1) * v->stride;
+    uint64_t blocks = (v->n + kBlock - 1) / kBlock;
+    dim3 grid((unsigned)std::min<uint64_t>(blocks, (uint64_t)v->num_slots));
+    HIP_TRY(launch_stats_flush_open(a, v->ep_return_f64, len_row, grid, c->compute));
+  }
+  hipError_t e;
+  if (v->is_acrobot64) e = launch_acrobot64_reset(a, 0, v->grid, c->compute);
+  else if (v->is_classic) e = launch_classic_reset(v->desc.env_id, a, v->grid, c->compute);
+  else if (v->is_tabular) e = launch_tabular_reset(v->desc.env_id, a, v->grid, c->compute);
+  else {
+    e = launch_pong_reset(a, v->grid, c->compute);
+    if (e == hipSuccess) e = launch_pong_raster(a, v->d_frames, c->compute);
+  }
+  if (e != hipSuccess) return fail(GX_ERR_HIP, "reset kernel launch failed: %s", hipGetErrorString(e));
+  v->tick += 1;
+  HIP_TRY(hipStreamSynchronize(c->compute));
+  return GX_OK;
+}
+
+extern "C" int gx_vec_get_state(gx_vec* v, void* host, size_t bytes) {
+  if (!v || !host) return fail(GX_ERR_INVALID, "gx_vec_get_state: null argument");
+  if (bytes != v->info.state_bytes) return fail(GX_ERR_INVALID, "gx_vec_get_state: buffer is %zu bytes, state image is %llu", bytes, (unsigned long long)v->info.state_bytes);
+  gx_ctx* c = v->ctx;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->compute));
+  const size_t rsz = dtype_size(v->info.real_dtype);
+  char* h = static_cast<char*>(host);
+  int rc = copy_rows(h, v->d_real, rsz, v->info.n_real, v->n, v->n, v->stride, hipMemcpyDeviceToHost, c->copy);
+  if (rc) return rc;
+  rc = copy_rows(h + (size_t)v->info.n_real * v->n * rsz, v->d_int, 4, v->info.n_int, v->n, v->n, v->stride, hipMemcpyDeviceToHost, c->copy);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(c->copy));
+  return GX_OK;
+}
+
+extern "C" int gx_vec_set_state(gx_vec* v, const void* host, size_t bytes) {
+  if (!v || !host) return fail(GX_ERR_INVALID, "gx_vec_set_state: null argument");
+  if (bytes != v->info.state_bytes) return fail(GX_ERR_INVALID, "gx_vec_set_state: buffer is %zu bytes, state image is %llu", bytes, (unsigned long long)v->info.state_bytes);
+  gx_ctx* c = v->ctx;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->compute));
+  const size_t rsz = dtype_size(v->info.real_dtype);
+  const char* h = static_cast<const char*>(host);
+  int rc = copy_rows(v->d_real, h, rsz, v->info.n_real, v->n, v->stride, v->n, hipMemcpyHostToDevice, c->copy);
+  if (rc) return rc;
+  rc = copy_rows(v->d_int, h + (size_t)v->info.n_real * v->n * rsz, 4, v->info.n_int, v->n, v->stride, v->n, hipMemcpyHostToDevice, c->copy);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(c->copy));
+  StepArgs a = make_args(v, nullptr, 1, 0);
+  if (v->is_pong) HIP_TRY(launch_pong_raster(a, v->d_frames, c->compute));
+  if (v->is_acrobot64) HIP_TRY(launch_acrobot64_reset(a, 1, v->grid, c->compute));
+  HIP_TRY(hipStreamSynchronize(c->compute));
+  return GX_OK;
+}
+
+// enqueue the device->host copy of the observation on `stream`
+static int copy_obs(gx_vec* v, void* host, hipStream_t stream) {
+  const gx_info& in = v->info;
+  if (v->is_pong) {
+    HIP_TRY(hipMemcpyAsync(host, v->d_frames, in.obs_bytes, hipMemcpyDeviceToHost, stream));
+    return GX_OK;
+  }
+  if (v->is_tabular) {
+    HIP_TRY(hipMemcpyAsync(host, v->d_int, v->n * 4, hipMemcpyDeviceToHost, stream));
+    return GX_OK;
+  }
+  const void* src = v->is_acrobot64 ? (const void*)v->d_obs : (const void*)v->d_real;
+  return copy_rows(host, src, 4, in.obs_dim, v->n, v->n, v->stride, hipMemcpyDeviceToHost, stream);
+}
+
+extern "C" int gx_vec_get_obs(gx_vec* v, void* host, size_t bytes) {
+  if (!v || !host) return fail(GX_ERR_INVALID, "gx_vec_get_obs: null argument");
+  if (bytes != v->info.obs_bytes) return fail(GX_ERR_INVALID, "gx_vec_get_obs: buffer is %zu bytes, observation is %llu", bytes, (unsigned long long)v->info.obs_bytes);
+  gx_ctx* c = v->ctx;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->compute));
+  int rc = copy_obs(v, host, c->copy);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(c->copy));
+  return GX_OK;
+}
+
+extern "C" int gx_vec_step_async(gx_vec* v, const void* h_actions, void* h_obs, void* h_reward, uint8_t* h_done,
+                                 uint8_t* h_truncated) {
+  if (!v || !h_actions) return fail(GX_ERR_INVALID, "gx_vec_step_async: null argument");
+  if (h_truncated && !v->d_trunc) return fail(GX_ERR_INVALID, "gx_vec_step_async: truncated requested but the batch has no time limit");
+  gx_ctx* c = v->ctx;
+  HIP_TRY(hipSetDevice(c->device));
+  if (v->desc.env_id == GX_ENV_ACROBOT) {
+    // torque[action] throws IndexOutOfRangeException (Envs.Acrobot.cs:45,51);
+    // the whole call is rejected before any env is stepped
+    const int32_t* act = static_cast<const int32_t*>(h_actions);
+    for (uint64_t i = 0; i < v->n; i++)
+      if ((uint32_t)act[i] > 2u) return fail(GX_ERR_INVALID, "Acrobot: action %d of env %llu is outside {0,1,2}", act[i], (unsigned long long)i);
+  }
+  HIP_TRY(hipMemcpyAsync(v->d_actions, h_actions, v->n * 4, hipMemcpyHostToDevice, c->copy));
+  HIP_TRY(hipEventRecord(c->ev_in, c->copy));
+  HIP_TRY(hipStreamWaitEvent(c->compute, c->ev_in, 0));
+  int rc = launch_step(v, v->d_actions, 1, v->stride, GX_POLICY_DEVICE_ACTIONS, c->compute);
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(c->ev_out, c->compute));
+  HIP_TRY(hipStreamWaitEvent(c->copy, c->ev_out, 0));
+  if (h_obs) {
+    rc = copy_obs(v, h_obs, c->copy);
+    if (rc) return rc;
+  }
+  if (h_reward) HIP_TRY(hipMemcpyAsync(h_reward, v->d_reward, v->n * dtype_size(v->info.reward_dtype), hipMemcpyDeviceToHost, c->copy));
+  if (h_done) HIP_TRY(hipMemcpyAsync(h_done, v->d_done, v->n, hipMemcpyDeviceToHost, c->copy));
+  if (h_truncated) HIP_TRY(hipMemcpyAsync(h_truncated, v->d_trunc, v->n, hipMemcpyDeviceToHost, c->copy));
+  return GX_OK;
+}
+
+extern "C" int gx_vec_wait(gx_vec* v) {
+  if (!v) return fail(GX_ERR_INVALID, "gx_vec_wait: null batch");
+  gx_ctx* c = v->ctx;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->compute));
+  HIP_TRY(hipMemcpyAsync(v->h_error, v->d_error, 4, hipMemcpyDeviceToHost, c->copy));
+  HIP_TRY(hipStreamSynchronize(c->copy));
+  if (*v->h_error) {
+    *v->h_error = 0;
+    HIP_TRY(hipMemsetAsync(v->d_error, 0, 4, c->copy));
+    HIP_TRY(hipStreamSynchronize(c->copy));
+    return fail(GX_ERR_INVALID, "a step since the last wait received an action outside the action space where the reference throws");
+  }
+  return GX_OK;
+}
+
+extern "C" int gx_vec_step_device(gx_vec* v, const void* d_actions, void* stream) {
+  if (!v || !d_actions) return fail(GX_ERR_INVALID, "gx_vec_step_device: null argument");
+  if ((uintptr_t)d_actions & 15) return fail(GX_ERR_INVALID, "gx_vec_step_device: d_actions must be 16-byte aligned");
+  HIP_TRY(hipSetDevice(v->ctx->device));
+  return launch_step(v, d_actions, 1, v->stride, GX_POLICY_DEVICE_ACTIONS, stream ? (hipStream_t)stream : v->ctx->compute);
+}
+
+extern "C" int gx_vec_step_random(gx_vec* v, void* stream) {
+  if (!v) return fail(GX_ERR_INVALID, "gx_vec_step_random: null batch");
+  HIP_TRY(hipSetDevice(v->ctx->device));
+  return launch_step(v, nullptr, 1, 0, GX_POLICY_RANDOM, stream ? (hipStream_t)stream : v->ctx->compute);
+}
+
+extern "C" int gx_vec_rollout(gx_vec* v, int k_steps, int policy, const void* d_actions, void* stream) {
+  if (!v) return fail(GX_ERR_INVALID, "gx_vec_rollout: null batch");
+  if (k_steps <= 0) return fail(GX_ERR_INVALID, "gx_vec_rollout: k_steps must be positive");
+  if (policy != GX_POLICY_RANDOM && policy != GX_POLICY_DEVICE_ACTIONS) return fail(GX_ERR_INVALID, "gx_vec_rollout: unknown policy %d", policy);
+  if (policy == GX_POLICY_DEVICE_ACTIONS) {
+    if (!d_actions) return fail(GX_ERR_INVALID, "gx_vec_rollout: DEVICE_ACTIONS needs d_actions[k_steps][stride]");
+    if ((uintptr_t)d_actions & 15) return fail(GX_ERR_INVALID, "gx_vec_rollout: d_actions must be 16-byte aligned");
+  }
+  HIP_TRY(hipSetDevice(v->ctx->device));
+  return launch_step(v, d_actions, k_steps, v->stride, policy, stream ? (hipStream_t)stream : v->ctx->compute);
+}
+
+extern "C" int gx_vec_sample_actions(gx_vec* v, uint64_t tick, void* d_actions, void* stream) {
+  if (!v || !d_actions) return fail(GX_ERR_INVALID, "gx_vec_sample_actions: null argument");
+  HIP_TRY(hipSetDevice(v->ctx->device));
+  return launch_sample(v, tick, d_actions, stream ? (hipStream_t)stream : v->ctx->compute);
+}
+
+extern "C" int gx_vec_device_view(gx_vec* v, gx_view* out) {
+  if (!v || !out) return fail(GX_ERR_INVALID, "gx_vec_device_view: null argument");
+  out->num_envs = v->n;
+  out->stride = v->stride;
+  out->state_real = v->d_real;
+  out->state_int = v->d_int;
+  out->obs = v->is_pong ? (void*)v->d_frames : (v->is_acrobot64 ? (void*)v->d_obs : (v->is_tabular ? (void*)v->d_int : v->d_real));
+  out->reward = v->d_reward;
+  out->done = v->d_done;
+  out->truncated = v->d_trunc;
+  return GX_OK;
+}
+
+static int reduce_stats(gx_vec* v, hipStream_t stream) {
+  if (!(v->desc.flags & GX_RECORD_STATS)) return fail(GX_ERR_INVALID, "the batch was created without GX_RECORD_STATS");
+  HIP_TRY(launch_stats_reduce(v->d_slots, v->num_slots, v->d_slots + v->num_slots, stream));
+  return GX_OK;
+}
+
+extern "C" int gx_vec_stats(gx_vec* v, gx_stats* out) {
+  if (!v || !out) return fail(GX_ERR_INVALID, "gx_vec_stats: null argument");
+  gx_ctx* c = v->ctx;
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = reduce_stats(v, c->compute);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(v->h_stat, v->d_slots + v->num_slots, sizeof(StatSlot), hipMemcpyDeviceToHost, c->compute));
+  HIP_TRY(hipStreamSynchronize(c->compute));
+  out->episodes = v->h_stat->episodes;
+  out->sum_return = v->h_stat->sum_return;
+  out->sum_length = v->h_stat->sum_length;
+  out->sum_return_sq = v->h_stat->sum_return_sq;
+  out->min_return = v->h_stat->min_return;
+  out->max_return = v->h_stat->max_return;
+  return GX_OK;
+}
+
+// --------------------------------------------------------------------- RCCL ---
+// librccl is opened on first use so that single-GPU users never load it.
+namespace {
+typedef int (*fn_get_unique_id)(void*);
+struct UniqueId {  // ncclUniqueId, passed by value
+  char internal[128];
+};
+typedef int (*fn_comm_init_rank_t)(void**, int, UniqueId, int);
+typedef int (*fn_comm_destroy)(void*);
+typedef int (*fn_all_reduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*fn_group)(void);
+typedef const char* (*fn_error_string)(int);
+constexpr int kNcclFloat64 = 8, kNcclSum = 0, kNcclMax = 2;
+
+void* open_rccl() {
+  void* lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+  if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
+  return lib;
+}
+}  // namespace
+
+extern "C" int gx_comm_unique_id(void* id128) {
+  if (!id128) return fail(GX_ERR_INVALID, "gx_comm_unique_id: null argument");
+  void* lib = open_rccl();
+  if (!lib) return fail(GX_ERR_RCCL, "cannot load librccl.so: %s", dlerror());
+  auto get = (fn_get_unique_id)dlsym(lib, "ncclGetUniqueId");
+  if (!get) return fail(GX_ERR_RCCL, "librccl.so has no ncclGetUniqueId");
+  int rc = get(id128);
+  if (rc != 0) return fail(GX_ERR_RCCL, "ncclGetUniqueId failed with %d", rc);
+  return GX_OK;
+}
+
+extern "C" int gx_comm_destroy(gx_comm* m) {
+  if (!m) return GX_OK;
+  if (m->ctx) (void)hipSetDevice(m->ctx->device);
+  if (m->comm && m->lib) {
+    auto destroy = (fn_comm_destroy)dlsym(m->lib, "ncclCommDestroy");
+    if (destroy) (void)destroy(m->comm);
+  }
+  if (m->d_buf) (void)hipFree(m->d_buf);
+  if (m->h_buf) (void)hipHostFree(m->h_buf);
+  delete m;
+  return GX_OK;
+}
+
+extern "C" int gx_comm_init(gx_ctx* ctx, const void* id128, int rank, int world, gx_comm** out) {
+  if (!ctx || !id128 || !out) return fail(GX_ERR_INVALID, "gx_comm_init: null argument");
+  *out = nullptr;
+  if (world < 1 || rank < 0 || rank >= world) return fail(GX_ERR_INVALID, "gx_comm_init: rank %d of %d", rank, world);
+  HIP_TRY(hipSetDevice(ctx->device));
+  gx_comm* m = new (std::nothrow) gx_comm();
+  if (!m) return fail(GX_ERR_OOM, "gx_comm_init: host allocation failed");
+  m->ctx = ctx;
+  m->rank = rank;
+  m->world = world;
+  m->lib = open_rccl();
+  if (!m->lib) {
+    gx_comm_destroy(m);
+    return fail(GX_ERR_RCCL, "cannot load librccl.so: %s", dlerror());
+  }
+  auto init = (fn_comm_init_rank_t)dlsym(m->lib, "ncclCommInitRank");
+  if (!init) {
+    gx_comm_destroy(m);
+    return fail(GX_ERR_RCCL, "librccl.so has no ncclCommInitRank");
+  }
+  UniqueId id;
+  std::memcpy(id.internal, id128, sizeof id.internal);
+  int rc = init(&m->comm, world, id, rank);
+  if (rc != 0) {
+    m->comm = nullptr;
+    gx_comm_destroy(m);
+    return fail(GX_ERR_RCCL, "ncclCommInitRank failed with %d", rc);
+  }
+  hipError_t e = hipMalloc((void**)&m->d_buf, 8 * sizeof(double));
+  if (e == hipSuccess) e = hipHostMalloc((void**)&m->h_buf, 8 * sizeof(double), hipHostMallocDefault);
+  if (e != hipSuccess) {
+    gx_comm_destroy(m);
+    return fail(GX_ERR_HIP, "gx_comm_init: buffer allocation failed: %s", hipGetErrorString(e));
+  }
+  *out = m;
+  return GX_OK;
+}
+
+extern "C" int gx_stats_allreduce(gx_comm* m, gx_vec* v, gx_stats* out) {
+  if (!m || !v || !out) return fail(GX_ERR_INVALID, "gx_stats_allreduce: null argument");
+  gx_stats local;
+  int rc = gx_vec_stats(v, &local);
+  if (rc) return rc;
+  gx_ctx* c = m->ctx;
+  // counts are exact in double below 2^53; min is reduced as max of the negation
+  m->h_buf[0] = (double)local.episodes;
+  m->h_buf[1] = (double)local.sum_length;
+  m->h_buf[2] = local.sum_return;
+  m->h_buf[3] = local.sum_return_sq;
+  m->h_buf[4] = -local.min_return;
+  m->h_buf[5] = local.max_return;
+  HIP_TRY(hipMemcpyAsync(m->d_buf, m->h_buf, 6 * sizeof(double), hipMemcpyHostToDevice, c->compute));
+  auto all_reduce = (fn_all_reduce)dlsym(m->lib, "ncclAllReduce");
+  auto group_start = (fn_group)dlsym(m->lib, "ncclGroupStart");
+  auto group_end = (fn_group)dlsym(m->lib, "ncclGroupEnd");
+  if (!all_reduce || !group_start || !group_end) return fail(GX_ERR_RCCL, "librccl.so lacks ncclAllReduce/ncclGroupStart/ncclGroupEnd");
+  int r0 = group_start();
+  int r1 = all_reduce(m->d_buf, m->d_buf, 4, kNcclFloat64, kNcclSum, m->comm, c->compute);
+  int r2 = all_reduce(m->d_buf + 4, m->d_buf + 4, 2, kNcclFloat64, kNcclMax, m->comm, c->compute);
+  int r3 = group_end();
+  if (r0 || r1 || r2 || r3) return fail(GX_ERR_RCCL, "ncclAllReduce failed (%d %d %d %d)", r0, r1, r2, r3);
+  HIP_TRY(hipMemcpyAsync(m->h_buf, m->d_buf, 6 * sizeof(double), hipMemcpyDeviceToHost, c->compute));
+  HIP_TRY(hipStreamSynchronize(c->compute));
+  out->episodes = (int64_t)m->h_buf[0];
+  out->sum_length = (int64_t)m->h_buf[1];
+  out->sum_return = m->h_buf[2];
+  out->sum_return_sq = m->h_buf[3];
+  out->min_return = -m->h_buf[4];
+  out->max_return = m->h_buf[5];
+  return GX_OK;
+}

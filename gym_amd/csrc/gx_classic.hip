@@ -1,0 +1,328 @@
+// Classic-control dynamics as gfx950 kernels: CartPole, MountainCar,
+// MountainCarContinuous, Pendulum, Acrobot (the reference's semi-implicit
+// Euler form).  Four consecutive envs per lane: every SoA row is read and
+// written as one 16-byte vector per lane.
+//
+// EXACT mode reproduces the C# source operation for operation: every
+// `float op float` is one binary32 operation (this file is compiled with
+// -ffp-contract=off so nothing is fused), Math.Sin/Cos/Atan2 are evaluated in
+// binary64 and rounded once by the (float) cast.
+#pragma clang fp contract(off)
+
+#include "gx_classic_kernel.h"
+
+namespace gx {
+
+// ------------------------------------------------------------------ envs ---
+// Each env: NS real components, action type, reward type, Reset and Step that
+// follow the cited reference lines.  `steps` is the env's own `_steps` field.
+
+struct CartPole {
+  static constexpr int NS = 4;
+  using Real = float;
+  static constexpr int W = 4;
+  static constexpr bool kDerivedObs = false;
+  static constexpr int NOBS = 4;
+  using Act = int32_t;
+  using Rew = float;
+  using EpRet = int32_t;
+  static constexpr bool kCheckAction = false;
+  static __device__ __forceinline__ bool action_valid(Act) { return true; }
+  static constexpr int NACT = 2;
+
+  // Envs.CartPole.cs:22-32
+  static __device__ __forceinline__ void reset(float (&s)[NS], const RngKey& key, uint64_t env) {
+    Draws d0 = philox_block(key, env, 0, 0), d1 = philox_block(key, env, 0, 1);
+    s[0] = (float)(d0.uniform(0) * 0.1 - 0.05);
+    s[1] = (float)(d0.uniform(1) * 0.1 - 0.05);
+    s[2] = (float)(d1.uniform(0) * 0.1 - 0.05);
+    s[3] = (float)(d1.uniform(1) * 0.1 - 0.05);
+  }
+
+  // Envs.CartPole.cs:34-75
+  template <int MODE>
+  static __device__ __forceinline__ void step(float (&s)[NS], int32_t& steps, Act action, Rew& reward, bool& done) {
+    const float gravity = 9.8f;
+    const float masscart = 1.0f;
+    const float masspole = 0.1f;
+    const float total_mass = masscart + masspole;
+    const float length = 0.5f;
+    const float polemass_length = masspole * length;
+    const float force_mag = 10.0f;
+    const float tau = 0.02f;
+    const float theta_threshold_radians = 12 * (float)M_PI / 180;
+    const float x_threshold = 2.4f;
+
+    float x = s[0], xDot = s[1], theta = s[2], thetaDot = s[3];
+    float force = action == 1 ? force_mag : -force_mag;
+    float sintheta, costheta;
+    Trig<MODE>::sincos(theta, sintheta, costheta);
+
+    float temp = (force + polemass_length * thetaDot * thetaDot * sintheta) / total_mass;
+    float thetaacc = (gravity * sintheta - costheta * temp) /
+                     (length * (4.0f / 3.0f - masspole * costheta * costheta / total_mass));
+    float xacc = temp - polemass_length * thetaacc * costheta / total_mass;
+
+    x += tau * xDot;
+    xDot += tau * xacc;
+    theta += tau * thetaDot;
+    thetaDot += tau * thetaacc;
+    s[0] = x; s[1] = xDot; s[2] = theta; s[3] = thetaDot;
+    steps++;
+
+    done = x < -x_threshold || x > x_threshold || theta < -theta_threshold_radians ||
+           theta > theta_threshold_radians || steps >= 500;
+    reward = !done ? 1.0f : 0.0f;
+  }
+  static __device__ __forceinline__ Act sample(const Draws& d) { return d.below(0, NACT); }
+};
+
+struct MountainCar {
+  static constexpr int NS = 2;
+  using Real = float;
+  static constexpr int W = 4;
+  static constexpr bool kDerivedObs = false;
+  static constexpr int NOBS = 2;
+  using Act = int32_t;
+  using Rew = float;
+  using EpRet = int32_t;
+  static constexpr bool kCheckAction = false;
+  static __device__ __forceinline__ bool action_valid(Act) { return true; }
+  static constexpr int NACT = 3;
+
+  // Envs.MountainCar.cs:22-30
+  static __device__ __forceinline__ void reset(float (&s)[NS], const RngKey& key, uint64_t env) {
+    Draws d0 = philox_block(key, env, 0, 0);
+    s[0] = (float)(d0.uniform(0) * 0.2 - 0.6);
+    s[1] = 0.0f;
+  }
+
+  // Envs.MountainCar.cs:32-50
+  template <int MODE>
+  static __device__ __forceinline__ void step(float (&s)[NS], int32_t& steps, Act action, Rew& reward, bool& done) {
+    float position = s[0], velocity = s[1];
+    float force = (float)(action - 1);
+    velocity += 0.001f * force - 0.0025f * Trig<MODE>::cos(3 * position);
+    velocity = clampf(velocity, -0.07f, 0.07f);
+    position += velocity;
+    if (position < -1.2f) {
+      position = -1.2f;
+      velocity = 0.0f;
+    }
+    done = position >= 0.5f;
+    reward = done ? 0.0f : -1.0f;
+    s[0] = position; s[1] = velocity;
+    steps++;
+  }
+  static __device__ __forceinline__ Act sample(const Draws& d) { return d.below(0, NACT); }
+};
+
+struct MountainCarContinuous {
+  static constexpr int NS = 2;
+  using Real = float;
+  static constexpr int W = 4;
+  static constexpr bool kDerivedObs = false;
+  static constexpr int NOBS = 2;
+  using Act = float;
+  using Rew = double;  // `velocity * 0.1` is a double product in the reference
+  using EpRet = double;
+  static constexpr bool kCheckAction = false;
+  static __device__ __forceinline__ bool action_valid(Act) { return true; }
+
+  // Envs.MountainCarContinuous.cs:19-27
+  static __device__ __forceinline__ void reset(float (&s)[NS], const RngKey& key, uint64_t env) {
+    MountainCar::reset(s, key, env);
+  }
+
+  // Envs.MountainCarContinuous.cs:29-49
+  template <int MODE>
+  static __device__ __forceinline__ void step(float (&s)[NS], int32_t& steps, Act action, Rew& reward, bool& done) {
+    float position = s[0], velocity = s[1];
+    float force = clampf(action, -1.0f, 1.0f);
+    velocity += force * 0.0015f - 0.0025f * Trig<MODE>::cos(3 * position);
+    velocity = clampf(velocity, -0.07f, 0.07f);
+    position += velocity;
+    if (position < -1.2f) {
+      position = -1.2f;
+      velocity = 0.0f;
+    }
+    done = position >= 0.45f;
+    double r = (double)velocity * 0.1;
+    if (done) r += 100.0;
+    reward = r;
+    s[0] = position; s[1] = velocity;
+    steps++;
+  }
+  // Box([-1],[1]), Envs.MountainCarContinuous.cs:12
+  static __device__ __forceinline__ Act sample(const Draws& d) { return box_sample(d.uniform(0), -1.0f, 1.0f); }
+};
+
+struct Pendulum {
+  static constexpr int NS = 3;
+  using Real = float;
+  static constexpr int W = 4;
+  static constexpr bool kDerivedObs = false;
+  static constexpr int NOBS = 3;
+  using Act = float;
+  using Rew = double;
+  using EpRet = double;
+  static constexpr bool kCheckAction = false;
+  static __device__ __forceinline__ bool action_valid(Act) { return true; }
+
+  // Envs.Pendulum.cs:19-28
+  static __device__ __forceinline__ void reset(float (&s)[NS], const RngKey& key, uint64_t env) {
+    Draws d0 = philox_block(key, env, 0, 0);
+    float theta = (float)(d0.uniform(0) * 2 * M_PI - M_PI);
+    float thetaDot = (float)(d0.uniform(1) * 1 - 0.5);
+    Trig<GX_MODE_EXACT>::sincos(theta, s[1], s[0]);
+    s[2] = thetaDot;
+  }
+
+  // Envs.Pendulum.cs:30-60
+  template <int MODE>
+  static __device__ __forceinline__ void step(float (&s)[NS], int32_t& steps, Act action, Rew& reward, bool& done) {
+    const float max_speed = 8.0f;
+    const float max_torque = 2.0f;
+    const float dt = 0.05f;
+    const float g = 10.0f;
+    const float m = 1.0f;
+    const float l = 1.0f;
+
+    float theta = Trig<MODE>::atan2(s[1], s[0]);
+    float thetaDot = s[2];
+    float u = clampf(action, -max_torque, max_torque);
+
+    float new_thetaDot = thetaDot + (-3 * g / (2 * l) * Trig<MODE>::sin_plus_pi(theta) + 3.0f / (m * l * l) * u) * dt;
+    new_thetaDot = clampf(new_thetaDot, -max_speed, max_speed);
+    float new_theta = theta + new_thetaDot * dt;
+
+    Trig<MODE>::sincos(new_theta, s[1], s[0]);
+    s[2] = new_thetaDot;
+    steps++;
+
+    // float*float promoted, then double products, summed left to right
+    reward = -((double)(theta * theta) + 0.1 * (double)thetaDot * (double)thetaDot + 0.001 * (double)u * (double)u);
+    done = false;
+  }
+  // Box([-2],[2]), Envs.Pendulum.cs:12
+  static __device__ __forceinline__ Act sample(const Draws& d) { return box_sample(d.uniform(0), -2.0f, 2.0f); }
+};
+
+struct Acrobot {
+  static constexpr int NS = 6;
+  using Real = float;
+  static constexpr int W = 4;
+  static constexpr bool kDerivedObs = false;
+  static constexpr int NOBS = 6;
+  using Act = int32_t;
+  using Rew = float;
+  using EpRet = int32_t;
+  static constexpr int NACT = 3;
+
+  // Envs.Acrobot.cs:22-28
+  static __device__ __forceinline__ void reset(float (&s)[NS], const RngKey& key, uint64_t env) {
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+      Draws d = philox_block(key, env, 0, b);
+      s[2 * b] = (float)(d.uniform(0) * 0.1 - 0.05);
+      s[2 * b + 1] = (float)(d.uniform(1) * 0.1 - 0.05);
+    }
+  }
+
+  // Envs.Acrobot.cs:30-91.  An action outside {0,1,2} throws in the reference
+  // (Envs.Acrobot.cs:51); the host validates before launch where it can and
+  // the kernel treats such a lane as torque 0.
+  template <int MODE>
+  static __device__ __forceinline__ void step(float (&s)[NS], int32_t& steps, Act action, Rew& reward, bool& done) {
+    const float LINK_LENGTH_1 = 1.0f;
+    const float LINK_LENGTH_2 = 1.0f;
+    const float LINK_MASS_1 = 1.0f;
+    const float LINK_MASS_2 = 1.0f;
+    const float LINK_COM_POS_1 = 0.5f;
+    const float LINK_COM_POS_2 = 0.5f;
+    const float LINK_MOI_1 = 1.0f;
+    const float LINK_MOI_2 = 1.0f;
+    const float MAX_VEL_1 = 4 * (float)M_PI;
+    const float MAX_VEL_2 = 9 * (float)M_PI;
+    const float dt = 0.2f;
+    const float g = 9.8f;
+
+    float theta1 = Trig<MODE>::atan2(s[1], s[0]);
+    float theta2 = Trig<MODE>::atan2(s[3], s[2]);
+    float dtheta1 = s[4];
+    float dtheta2 = s[5];
+    float u = action == 0 ? -1.0f : (action == 2 ? 1.0f : 0.0f);
+
+    float sin2, cos2;
+    Trig<MODE>::sincos(theta2, sin2, cos2);
+
+    float d1 = LINK_MASS_1 * LINK_COM_POS_1 * LINK_COM_POS_1 +
+               LINK_MASS_2 * (LINK_LENGTH_1 * LINK_LENGTH_1 + LINK_COM_POS_2 * LINK_COM_POS_2 +
+                              2 * LINK_LENGTH_1 * LINK_COM_POS_2 * cos2) +
+               LINK_MOI_1 + LINK_MOI_2;
+    float d2 = LINK_MASS_2 * (LINK_COM_POS_2 * LINK_COM_POS_2 + LINK_LENGTH_1 * LINK_COM_POS_2 * cos2) + LINK_MOI_2;
+    float phi2 = LINK_MASS_2 * LINK_COM_POS_2 * g * Trig<MODE>::cos_minus_half_pi(theta1 + theta2);
+    float phi1 = -LINK_MASS_2 * LINK_LENGTH_1 * LINK_COM_POS_2 * dtheta2 * dtheta2 * sin2 -
+                 2 * LINK_MASS_2 * LINK_LENGTH_1 * LINK_COM_POS_2 * dtheta2 * dtheta1 * sin2 +
+                 (LINK_MASS_1 * LINK_COM_POS_1 + LINK_MASS_2 * LINK_LENGTH_1) * g * Trig<MODE>::cos_minus_half_pi(theta1) +
+                 phi2;
+    float ddtheta2 = (u + d2 / d1 * phi1 - LINK_MASS_2 * LINK_LENGTH_1 * LINK_COM_POS_2 * dtheta1 * dtheta1 * sin2 - phi2) /
+                     (LINK_MASS_2 * LINK_COM_POS_2 * LINK_COM_POS_2 + LINK_MOI_2 - d2 * d2 / d1);
+    float ddtheta1 = -(d2 * ddtheta2 + phi1) / d1;
+
+    dtheta1 += dt * ddtheta1;
+    dtheta2 += dt * ddtheta2;
+    dtheta1 = clampf(dtheta1, -MAX_VEL_1, MAX_VEL_1);
+    dtheta2 = clampf(dtheta2, -MAX_VEL_2, MAX_VEL_2);
+    theta1 += dt * dtheta1;
+    theta2 += dt * dtheta2;
+
+    float c1n, s1n, c2n, s2n;
+    Trig<MODE>::sincos(theta1, s1n, c1n);
+    Trig<MODE>::sincos(theta2, s2n, c2n);
+    s[0] = c1n; s[1] = s1n; s[2] = c2n; s[3] = s2n; s[4] = dtheta1; s[5] = dtheta2;
+    steps++;
+
+    float tip_y = -LINK_LENGTH_1 * c1n - LINK_LENGTH_2 * Trig<MODE>::cos(theta1 + theta2);
+    done = tip_y > 1.0f || steps >= 500;
+    reward = done ? 0.0f : -1.0f;
+  }
+  static __device__ __forceinline__ Act sample(const Draws& d) { return d.below(0, NACT); }
+  static constexpr bool kCheckAction = true;
+  static __device__ __forceinline__ bool action_valid(Act a) { return (uint32_t)a <= 2u; }
+};
+
+hipError_t launch_classic_step(int env_id, const StepArgs& a, int mode, int policy, dim3 grid, hipStream_t stream) {
+  switch (env_id) {
+    case GX_ENV_CARTPOLE: return launch_step_env<CartPole>(a, mode, policy, grid, stream);
+    case GX_ENV_MOUNTAINCAR: return launch_step_env<MountainCar>(a, mode, policy, grid, stream);
+    case GX_ENV_MOUNTAINCAR_CONT: return launch_step_env<MountainCarContinuous>(a, mode, policy, grid, stream);
+    case GX_ENV_PENDULUM: return launch_step_env<Pendulum>(a, mode, policy, grid, stream);
+    case GX_ENV_ACROBOT: return launch_step_env<Acrobot>(a, mode, policy, grid, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_classic_reset(int env_id, const StepArgs& a, dim3 grid, hipStream_t stream) {
+  switch (env_id) {
+    case GX_ENV_CARTPOLE: return launch_reset_env<CartPole>(a, 0, grid, stream);
+    case GX_ENV_MOUNTAINCAR: return launch_reset_env<MountainCar>(a, 0, grid, stream);
+    case GX_ENV_MOUNTAINCAR_CONT: return launch_reset_env<MountainCarContinuous>(a, 0, grid, stream);
+    case GX_ENV_PENDULUM: return launch_reset_env<Pendulum>(a, 0, grid, stream);
+    case GX_ENV_ACROBOT: return launch_reset_env<Acrobot>(a, 0, grid, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_classic_sample(int env_id, const StepArgs& a, void* out, dim3 grid, hipStream_t stream) {
+  switch (env_id) {
+    case GX_ENV_CARTPOLE: return launch_sample_env<CartPole>(a, out, grid, stream);
+    case GX_ENV_MOUNTAINCAR: return launch_sample_env<MountainCar>(a, out, grid, stream);
+    case GX_ENV_MOUNTAINCAR_CONT: return launch_sample_env<MountainCarContinuous>(a, out, grid, stream);
+    case GX_ENV_PENDULUM: return launch_sample_env<Pendulum>(a, out, grid, stream);
+    case GX_ENV_ACROBOT: return launch_sample_env<Acrobot>(a, out, grid, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace gx

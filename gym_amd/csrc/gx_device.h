@@ -1,0 +1,215 @@
+// Shared device-side pieces of the batched environment engine: the counter
+// RNG, the fused-wrapper bookkeeping and the per-block statistics reduction.
+// gfx950 only; wavefront = 64.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gymx.h"
+
+namespace gx {
+
+constexpr int kBlock = 256;          // threads per workgroup (4 waves)
+constexpr int kEnvsPerThread = 4;    // one 16-byte vector per component per lane
+constexpr int kStatFields = 6;
+
+// ---------------------------------------------------------------------------
+// Counter RNG.  The reference's System.Random instances are unseeded
+// (Envs.CartPole.cs:19, Spaces.Box.cs:14) and Env.Seed is empty (Env.cs:33-36),
+// so the engine defines its own stream:
+//   Philox4x32-10, key = seed, counter = (env_lo, env_hi, tick_lo,
+//   stream << 24 | tick_hi8 << 16 | block);  draw d lives in block d/2, words
+//   (1:0) when d is even and (3:2) when d is odd;  u = (x >> 11) * 2^-53.
+// `tick` counts the Reset()/Step() calls made on the batch before the one that
+// consumes the draw, so no per-env RNG state is stored or moved.
+// Streams: 0 = Reset draws, 1 = draws made inside Step, 2 = random policy.
+// ---------------------------------------------------------------------------
+struct RngKey {
+  uint32_t k0, k1;     // seed
+  uint32_t tick_lo;
+  uint32_t tick_hi8;   // bits 32..39 of the tick, pre-shifted to bit 16
+};
+
+__device__ __forceinline__ RngKey make_key(uint32_t seed_lo, uint32_t seed_hi, uint64_t tick) {
+  RngKey k;
+  k.k0 = seed_lo;
+  k.k1 = seed_hi;
+  k.tick_lo = (uint32_t)tick;
+  k.tick_hi8 = ((uint32_t)(tick >> 32) & 0xFFu) << 16;
+  return k;
+}
+
+struct Draws {
+  uint32_t w[4];
+  __device__ __forceinline__ uint64_t u64(int half) const {
+    return half ? (((uint64_t)w[3] << 32) | w[2]) : (((uint64_t)w[1] << 32) | w[0]);
+  }
+  // uniform double in [0,1) with 53 random bits
+  __device__ __forceinline__ double uniform(int half) const {
+    return (double)(u64(half) >> 11) * 0x1.0p-53;
+  }
+  // Random.Next(n) stand-in: high word scaled by multiply-shift
+  __device__ __forceinline__ int32_t below(int half, uint32_t n) const {
+    return (int32_t)__umulhi(half ? w[3] : w[1], n);
+  }
+};
+
+__device__ __forceinline__ Draws philox_block(const RngKey& key, uint64_t env, uint32_t stream, uint32_t block) {
+  uint32_t c0 = (uint32_t)env, c1 = (uint32_t)(env >> 32), c2 = key.tick_lo;
+  uint32_t c3 = (stream << 24) | key.tick_hi8 | block;
+  uint32_t k0 = key.k0, k1 = key.k1;
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1;
+    c3 = (uint32_t)p0;
+    c0 = n0;
+    c2 = n2;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  Draws d;
+  d.w[0] = c0; d.w[1] = c1; d.w[2] = c2; d.w[3] = c3;
+  return d;
+}
+
+// Spaces.Box.cs:30 -- (float)(NextDouble() * (High - Low) + Low), the range
+// being a binary32 subtraction promoted to double.
+__device__ __forceinline__ float box_sample(double u, float low, float high) {
+  float range = high - low;
+  return (float)(u * (double)range + (double)low);
+}
+
+// ---------------------------------------------------------------------------
+// Episode statistics (RecordEpisodeStatistics, EnvWrapper.cs:23-58): every
+// thread accumulates the episodes its envs finished, a workgroup reduces them
+// and read-modify-writes its own slot, so the step needs no atomics.  Integer
+// valued returns stay exact in double, so those sums do not depend on order.
+// ---------------------------------------------------------------------------
+struct StatSlot {
+  long long episodes;
+  double sum_return;
+  long long sum_length;
+  double sum_return_sq;
+  double min_return;
+  double max_return;
+  long long pad[2];  // 64 bytes: one slot per cache line half
+};
+
+struct StatAcc {
+  long long episodes = 0;
+  double sum_return = 0.0;
+  long long sum_length = 0;
+  double sum_return_sq = 0.0;
+  double min_return = __builtin_huge_val();
+  double max_return = -__builtin_huge_val();
+
+  __device__ __forceinline__ void add(double ret, int len) {
+    episodes += 1;
+    sum_return += ret;
+    sum_length += len;
+    sum_return_sq += ret * ret;
+    min_return = ret < min_return ? ret : min_return;
+    max_return = ret > max_return ? ret : max_return;
+  }
+};
+
+__device__ __forceinline__ double shfl_down_f64(double v, int delta) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl_down(lo, delta, 64);
+  hi = __shfl_down(hi, delta, 64);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ long long shfl_down_i64(long long v, int delta) {
+  int lo = (int)(v & 0xFFFFFFFFll), hi = (int)(v >> 32);
+  lo = __shfl_down(lo, delta, 64);
+  hi = __shfl_down(hi, delta, 64);
+  return ((long long)hi << 32) | (unsigned int)lo;
+}
+
+// Called by every thread of the workgroup exactly once, at the end of the
+// kernel.  `slots` has one entry per workgroup of the largest grid the batch
+// ever launches.
+__device__ __forceinline__ void block_commit_stats(const StatAcc& mine, StatSlot* slots) {
+  __shared__ StatSlot wave_part[kBlock / 64];
+  StatAcc a = mine;
+  // a wave that finished no episode skips the shuffles
+  bool any = __any(a.episodes != 0);
+  if (any) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      a.episodes += shfl_down_i64(a.episodes, d);
+      a.sum_return += shfl_down_f64(a.sum_return, d);
+      a.sum_length += shfl_down_i64(a.sum_length, d);
+      a.sum_return_sq += shfl_down_f64(a.sum_return_sq, d);
+      double mn = shfl_down_f64(a.min_return, d), mx = shfl_down_f64(a.max_return, d);
+      a.min_return = mn < a.min_return ? mn : a.min_return;
+      a.max_return = mx > a.max_return ? mx : a.max_return;
+    }
+  }
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    StatSlot s;
+    s.episodes = a.episodes; s.sum_return = a.sum_return; s.sum_length = a.sum_length;
+    s.sum_return_sq = a.sum_return_sq; s.min_return = a.min_return; s.max_return = a.max_return;
+    s.pad[0] = s.pad[1] = 0;
+    wave_part[wave] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    StatSlot t = wave_part[0];
+#pragma unroll
+    for (int w = 1; w < kBlock / 64; w++) {
+      const StatSlot& o = wave_part[w];
+      t.episodes += o.episodes; t.sum_return += o.sum_return; t.sum_length += o.sum_length;
+      t.sum_return_sq += o.sum_return_sq;
+      t.min_return = o.min_return < t.min_return ? o.min_return : t.min_return;
+      t.max_return = o.max_return > t.max_return ? o.max_return : t.max_return;
+    }
+    if (t.episodes != 0) {
+      StatSlot g = slots[blockIdx.x];
+      g.episodes += t.episodes; g.sum_return += t.sum_return; g.sum_length += t.sum_length;
+      g.sum_return_sq += t.sum_return_sq;
+      g.min_return = t.min_return < g.min_return ? t.min_return : g.min_return;
+      g.max_return = t.max_return > g.max_return ? t.max_return : g.max_return;
+      slots[blockIdx.x] = g;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Arguments shared by the step / rollout kernels.  Component arrays are SoA,
+// `stride` elements apart, 16-byte aligned, padded to a multiple of four envs.
+// ---------------------------------------------------------------------------
+struct StepArgs {
+  void* state_real;        // [n_real][stride] float or double
+  int32_t* state_int;      // [n_int][stride], last row = step counter
+  const void* actions;     // int32/float [k_steps][action_stride]; unused for the random policy
+  void* reward;            // [stride] float or double
+  uint8_t* done;           // [stride]
+  uint8_t* truncated;      // [stride] or nullptr
+  void* ep_return;         // [stride] int32 or double; nullptr unless RECORD_STATS
+  int32_t* ep_length;      // [stride]; nullptr when the step counter serves (AUTORESET)
+  StatSlot* stat_slots;    // one per workgroup
+  float* obs;              // derived observation rows, or nullptr
+  const uint32_t* table;   // tabular envs: packed transition table
+  uint32_t* error_flag;    // set non-zero by a kernel that meets an action the reference throws on
+  uint64_t num_envs;
+  uint64_t stride;
+  uint64_t action_stride;
+  uint64_t env_index_base;
+  uint64_t tick;
+  uint32_t seed_lo, seed_hi;
+  uint32_t flags;          // gx_flags
+  int32_t time_limit;      // 0 = none
+  int32_t k_steps;         // 1 for a single step
+  int32_t table_states, table_actions, table_outcomes;
+  int32_t start_state;
+  int32_t step_limit;
+};
+
+}  // namespace gx

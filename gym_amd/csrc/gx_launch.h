@@ -1,0 +1,38 @@
+// Host-callable launchers implemented by the kernel translation units.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "gx_device.h"
+
+namespace gx {
+
+// classic control (gx_classic.hip)
+hipError_t launch_classic_step(int env_id, const StepArgs& a, int mode, int policy, dim3 grid, hipStream_t stream);
+hipError_t launch_classic_reset(int env_id, const StepArgs& a, dim3 grid, hipStream_t stream);
+hipError_t launch_classic_sample(int env_id, const StepArgs& a, void* out, dim3 grid, hipStream_t stream);
+
+// Acrobot, RK4 in binary64 (gx_acrobot64.hip)
+hipError_t launch_acrobot64_step(const StepArgs& a, int policy, dim3 grid, hipStream_t stream);
+hipError_t launch_acrobot64_reset(const StepArgs& a, int only_observe, dim3 grid, hipStream_t stream);
+hipError_t launch_acrobot64_sample(const StepArgs& a, void* out, dim3 grid, hipStream_t stream);
+
+// table-driven envs and DummyEnv (gx_tabular.hip)
+hipError_t launch_tabular_step(int env_id, const StepArgs& a, int policy, dim3 grid, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_tabular_reset(int env_id, const StepArgs& a, dim3 grid, hipStream_t stream);
+hipError_t launch_tabular_sample(int env_id, const StepArgs& a, void* out, dim3 grid, hipStream_t stream);
+
+// Pong (gx_pong.hip)
+hipError_t launch_pong_step(const StepArgs& a, int policy, dim3 grid, hipStream_t stream);
+hipError_t launch_pong_reset(const StepArgs& a, dim3 grid, hipStream_t stream);
+hipError_t launch_pong_raster(const StepArgs& a, uint8_t* frames, hipStream_t stream);
+hipError_t launch_pong_sample(const StepArgs& a, void* out, dim3 grid, hipStream_t stream);
+
+// statistics (gx_stats.hip)
+hipError_t launch_stats_reduce(const StatSlot* slots, int num_slots, StatSlot* out, hipStream_t stream);
+hipError_t launch_stats_init(StatSlot* slots, int num_slots, hipStream_t stream);
+// EnvWrapper.cs:34-38: Reset() with an open episode records it first
+hipError_t launch_stats_flush_open(const StepArgs& a, int ep_return_is_f64, const int32_t* length_row, dim3 grid,
+                                   hipStream_t stream);
+
+}  // namespace gx

@@ -1,0 +1,250 @@
+// Pong: game state stepped one env per lane in binary64, and the 210x160x3
+// frame of every env rasterised by a separate bandwidth-bound kernel.
+//
+// The reference clears a 100 800-byte array and draws ~30 rectangles with
+// per-pixel bounds checks on every step (Envs.Pong.cs:167-209).  Every drawn
+// pixel is (255,255,255), so draw order is irrelevant and the frame is a
+// binary mask: each lane derives four consecutive pixels of a row from the
+// object positions and writes them as one 12-byte store, a workgroup writing
+// one env's frame front to back with fully coalesced stores.
+#pragma clang fp contract(off)
+
+#include "gx_device.h"
+#include "gx_launch.h"
+
+namespace gx {
+
+constexpr int kScreenW = 160, kScreenH = 210, kFrameBytes = kScreenW * kScreenH * 3;
+constexpr double kPaddleSpeed = 4.0, kBallSpeed = 3.0;
+constexpr int kPaddleH = 15, kPaddleW = 2, kBallSize = 2;
+
+struct PongState {
+  double ballX, ballY, ballVelX, ballVelY, leftPaddleY, rightPaddleY;
+  int32_t leftScore, rightScore, steps;
+};
+
+// Envs.Pong.cs:159-165 (stream 0 from Reset, stream 1 from inside Step)
+__device__ __forceinline__ void pong_reset_ball(PongState& p, const RngKey& key, uint64_t env, uint32_t stream) {
+  Draws d = philox_block(key, env, stream, 0);
+  p.ballX = kScreenW / 2.0;
+  p.ballY = kScreenH / 2.0;
+  p.ballVelX = d.uniform(0) > 0.5 ? kBallSpeed : -kBallSpeed;
+  p.ballVelY = (d.uniform(1) - 0.5) * 2.0 * kBallSpeed;
+}
+
+// Envs.Pong.cs:54-70
+__device__ __forceinline__ void pong_reset(PongState& p, const RngKey& key, uint64_t env) {
+  pong_reset_ball(p, key, env, 0);
+  p.leftPaddleY = kScreenH / 2.0 - kPaddleH / 2.0;
+  p.rightPaddleY = kScreenH / 2.0 - kPaddleH / 2.0;
+  p.leftScore = 0;
+  p.rightScore = 0;
+  p.steps = 0;
+}
+
+// Math.Max / Math.Min on doubles (no NaN can occur here)
+__device__ __forceinline__ double dmax(double a, double b) { return a >= b ? a : b; }
+__device__ __forceinline__ double dmin(double a, double b) { return a <= b ? a : b; }
+
+// Envs.Pong.cs:72-145
+__device__ __forceinline__ void pong_step(PongState& p, int action, const RngKey& key, uint64_t env, float& reward, bool& done) {
+  p.steps++;
+  float rew = 0.0f;
+  if (action == 2) p.rightPaddleY = dmax(0, p.rightPaddleY - kPaddleSpeed);
+  else if (action == 3) p.rightPaddleY = dmin(kScreenH - kPaddleH, p.rightPaddleY + kPaddleSpeed);
+
+  const double ballCenterY = p.ballY + kBallSize / 2.0;
+  const double leftPaddleCenterY = p.leftPaddleY + kPaddleH / 2.0;
+  if (ballCenterY < leftPaddleCenterY - 2) p.leftPaddleY = dmax(0, p.leftPaddleY - kPaddleSpeed * 0.8);
+  else if (ballCenterY > leftPaddleCenterY + 2) p.leftPaddleY = dmin(kScreenH - kPaddleH, p.leftPaddleY + kPaddleSpeed * 0.8);
+
+  p.ballX += p.ballVelX;
+  p.ballY += p.ballVelY;
+
+  if (p.ballY <= 0 || p.ballY >= kScreenH - kBallSize) {
+    p.ballVelY = -p.ballVelY;
+    p.ballY = dmax(0, dmin(kScreenH - kBallSize, p.ballY));
+  }
+  if (p.ballX <= kPaddleW && p.ballY + kBallSize >= p.leftPaddleY && p.ballY <= p.leftPaddleY + kPaddleH) {
+    p.ballVelX = fabs(p.ballVelX);
+    const double rel = (p.leftPaddleY + kPaddleH / 2.0) - (p.ballY + kBallSize / 2.0);
+    p.ballVelY = -rel * 0.1;
+  }
+  if (p.ballX + kBallSize >= kScreenW - kPaddleW && p.ballY + kBallSize >= p.rightPaddleY &&
+      p.ballY <= p.rightPaddleY + kPaddleH) {
+    p.ballVelX = -fabs(p.ballVelX);
+    const double rel = (p.rightPaddleY + kPaddleH / 2.0) - (p.ballY + kBallSize / 2.0);
+    p.ballVelY = -rel * 0.1;
+  }
+  if (p.ballX < 0) {
+    p.rightScore++;
+    rew = 1.0f;
+    pong_reset_ball(p, key, env, 1);
+  } else if (p.ballX > kScreenW) {
+    p.leftScore++;
+    rew = -1.0f;
+    pong_reset_ball(p, key, env, 1);
+  }
+  done = p.leftScore >= 21 || p.rightScore >= 21 || p.steps >= 10000;
+  reward = rew;
+}
+
+__device__ __forceinline__ void pong_load(const StepArgs& a, uint64_t i, PongState& p) {
+  const double* r = static_cast<const double*>(a.state_real);
+  p.ballX = r[i]; p.ballY = r[a.stride + i]; p.ballVelX = r[2 * a.stride + i]; p.ballVelY = r[3 * a.stride + i];
+  p.leftPaddleY = r[4 * a.stride + i]; p.rightPaddleY = r[5 * a.stride + i];
+  p.leftScore = a.state_int[i]; p.rightScore = a.state_int[a.stride + i]; p.steps = a.state_int[2 * a.stride + i];
+}
+__device__ __forceinline__ void pong_store(const StepArgs& a, uint64_t i, const PongState& p) {
+  double* r = static_cast<double*>(a.state_real);
+  r[i] = p.ballX; r[a.stride + i] = p.ballY; r[2 * a.stride + i] = p.ballVelX; r[3 * a.stride + i] = p.ballVelY;
+  r[4 * a.stride + i] = p.leftPaddleY; r[5 * a.stride + i] = p.rightPaddleY;
+  a.state_int[i] = p.leftScore; a.state_int[a.stride + i] = p.rightScore; a.state_int[2 * a.stride + i] = p.steps;
+}
+
+template <int POLICY>
+__global__ void __launch_bounds__(kBlock) pong_step_kernel(StepArgs a) {
+  const bool autoreset = (a.flags & GX_AUTORESET) != 0;
+  const bool record = (a.flags & GX_RECORD_STATS) != 0;
+  StatAcc acc;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < a.num_envs; i += (uint64_t)gridDim.x * kBlock) {
+    PongState p;
+    pong_load(a, i, p);
+    int32_t ep_ret = 0, ep_len = 0;
+    if (record) {
+      ep_ret = static_cast<const int32_t*>(a.ep_return)[i];
+      if (a.ep_length) ep_len = a.ep_length[i];
+    }
+    const uint64_t env = a.env_index_base + i;
+    float reward = 0.0f;
+    bool done = false, trunc = false;
+    for (int k = 0; k < a.k_steps; k++) {
+      const RngKey key = make_key(a.seed_lo, a.seed_hi, a.tick + (uint64_t)k);
+      int act;
+      if (POLICY == GX_POLICY_RANDOM) act = philox_block(key, env, 2, 0).below(0, 4);  // Discrete(4), Envs.Pong.cs:36
+      else act = static_cast<const int32_t*>(a.actions)[(uint64_t)k * a.action_stride + i];
+      pong_step(p, act, key, env, reward, done);
+      trunc = a.time_limit > 0 && p.steps >= a.time_limit;  // Wrappers.TimeLimit.cs:26-31
+      done = done || trunc;
+      if (record) {  // EnvWrapper.cs:46-55
+        ep_ret += (int32_t)reward;
+        ep_len += 1;
+        if (done) {
+          acc.add((double)ep_ret, a.ep_length ? ep_len : p.steps);
+          ep_ret = 0;
+          ep_len = 0;
+        }
+      }
+      if (autoreset && done) pong_reset(p, key, env);
+    }
+    pong_store(a, i, p);
+    if (record) {
+      static_cast<int32_t*>(a.ep_return)[i] = ep_ret;
+      if (a.ep_length) a.ep_length[i] = ep_len;
+    }
+    static_cast<float*>(a.reward)[i] = reward;
+    a.done[i] = done;
+    if (a.truncated) a.truncated[i] = trunc;
+  }
+  if (record) block_commit_stats(acc, a.stat_slots);
+}
+
+__global__ void __launch_bounds__(kBlock) pong_reset_kernel(StepArgs a) {
+  const RngKey key = make_key(a.seed_lo, a.seed_hi, a.tick);
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < a.num_envs; i += (uint64_t)gridDim.x * kBlock) {
+    PongState p;
+    pong_reset(p, key, a.env_index_base + i);
+    pong_store(a, i, p);
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) pong_sample_kernel(StepArgs a, int32_t* out) {
+  const RngKey key = make_key(a.seed_lo, a.seed_hi, a.tick);
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < a.num_envs; i += (uint64_t)gridDim.x * kBlock)
+    out[i] = philox_block(key, a.env_index_base + i, 2, 0).below(0, 4);
+}
+
+// 3x5 digit glyphs of Envs.Pong.cs:228-237, one byte per row, bit dx = column dx.
+__constant__ uint8_t kGlyphRows[10][5] = {
+    {7, 5, 5, 5, 7}, {2, 3, 2, 2, 7}, {7, 4, 7, 1, 7}, {7, 4, 7, 4, 7}, {5, 5, 7, 4, 4},
+    {7, 1, 7, 4, 7}, {7, 1, 7, 5, 7}, {7, 4, 4, 4, 4}, {7, 5, 7, 5, 7}, {7, 5, 7, 4, 7}};
+
+struct U3 {
+  uint32_t x, y, z;
+};
+
+// One workgroup per env.  A frame row is 160 pixels = 40 groups of four
+// pixels = 40 lanes x 12 bytes; the frame is 8400 such groups.
+__global__ void __launch_bounds__(kBlock) pong_raster_kernel(StepArgs a, uint8_t* __restrict__ frames) {
+  __shared__ uint32_t digit_rows[5][5];  // rows 20..24 of the frame as 160-bit masks
+  const uint64_t env = blockIdx.x;
+  const double* r = static_cast<const double*>(a.state_real);
+  // (int) casts truncate toward zero, Envs.Pong.cs:173-179
+  const int bx = (int)r[env], by = (int)r[a.stride + env];
+  const int ly = (int)r[4 * a.stride + env], ry = (int)r[5 * a.stride + env];
+  if (threadIdx.x < 25) digit_rows[threadIdx.x / 5][threadIdx.x % 5] = 0;
+  __syncthreads();
+  if (threadIdx.x < 10) {
+    // Envs.Pong.cs:211-251: decimal string, digit i at startX + 8 i, rows y0..y0+4
+    const int side = threadIdx.x / 5, row = threadIdx.x % 5;
+    const int score = a.state_int[(uint64_t)side * a.stride + env];
+    const int centerX = side ? 3 * kScreenW / 4 : kScreenW / 4;
+    uint32_t mag = score < 0 ? 0u - (uint32_t)score : (uint32_t)score;
+    int ndig = 1;
+    for (uint32_t t = mag; t >= 10; t /= 10) ndig++;
+    const int len = ndig + (score < 0 ? 1 : 0);  // a '-' occupies a cell and draws nothing
+    const int startX = centerX - (len * 6) / 2;
+    for (int i = len - 1; i >= len - ndig; i--) {
+      const uint32_t g = kGlyphRows[mag % 10][row];
+      mag /= 10;
+#pragma unroll
+      for (int dx = 0; dx < 3; dx++) {
+        const int px = startX + 8 * i + dx;
+        if (((g >> dx) & 1u) && px >= 0 && px < kScreenW) atomicOr(&digit_rows[row][px >> 5], 1u << (px & 31));
+      }
+    }
+  }
+  __syncthreads();
+
+  uint8_t* frame = frames + env * (uint64_t)kFrameBytes;
+  for (int c = threadIdx.x; c < kScreenH * 40; c += kBlock) {
+    const int y = c / 40, g = c - y * 40;
+    uint32_t nib = 0;
+    if (g == 0 && y >= ly && y < ly + kPaddleH) nib |= 0x3u;           // left paddle, x in {0,1}
+    if (g == 39 && y >= ry && y < ry + kPaddleH) nib |= 0xCu;          // right paddle, x in {158,159}
+    if ((y & 7) < 4) nib |= g == 19 ? 0x8u : (g == 20 ? 0x1u : 0u);    // centre dashes, x in {79,80}
+    if (y == by || y == by + 1) {                                      // ball, x in {bx, bx+1}
+      const int rel = bx - 4 * g;
+      if (rel >= -1 && rel <= 3) nib |= ((0x3u << (rel + 1)) >> 1) & 0xFu;
+    }
+    if (y >= 20 && y < 25) nib |= (digit_rows[y - 20][g >> 3] >> (4 * (g & 7))) & 0xFu;
+    // four pixels -> twelve bytes, three bytes of 0xFF per set pixel
+    const uint32_t p0 = 0u - (nib & 1u), p1 = 0u - ((nib >> 1) & 1u), p2 = 0u - ((nib >> 2) & 1u), p3 = 0u - ((nib >> 3) & 1u);
+    U3 v;
+    v.x = (p0 & 0x00FFFFFFu) | (p1 & 0xFF000000u);
+    v.y = (p1 & 0x0000FFFFu) | (p2 & 0xFFFF0000u);
+    v.z = (p2 & 0x000000FFu) | (p3 & 0xFFFFFF00u);
+    *reinterpret_cast<U3*>(frame + (uint64_t)c * 12) = v;
+  }
+}
+
+hipError_t launch_pong_step(const StepArgs& a, int policy, dim3 grid, hipStream_t stream) {
+  if (policy == GX_POLICY_RANDOM) hipLaunchKernelGGL(pong_step_kernel<GX_POLICY_RANDOM>, grid, dim3(kBlock), 0, stream, a);
+  else hipLaunchKernelGGL(pong_step_kernel<GX_POLICY_DEVICE_ACTIONS>, grid, dim3(kBlock), 0, stream, a);
+  return hipGetLastError();
+}
+hipError_t launch_pong_reset(const StepArgs& a, dim3 grid, hipStream_t stream) {
+  hipLaunchKernelGGL(pong_reset_kernel, grid, dim3(kBlock), 0, stream, a);
+  return hipGetLastError();
+}
+hipError_t launch_pong_raster(const StepArgs& a, uint8_t* frames, hipStream_t stream) {
+  if (a.num_envs == 0) return hipSuccess;
+  hipLaunchKernelGGL(pong_raster_kernel, dim3((unsigned)a.num_envs), dim3(kBlock), 0, stream, a, frames);
+  return hipGetLastError();
+}
+hipError_t launch_pong_sample(const StepArgs& a, void* out, dim3 grid, hipStream_t stream) {
+  hipLaunchKernelGGL(pong_sample_kernel, grid, dim3(kBlock), 0, stream, a, static_cast<int32_t*>(out));
+  return hipGetLastError();
+}
+
+}  // namespace gx

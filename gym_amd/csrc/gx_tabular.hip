@@ -1,0 +1,239 @@
+// Table-driven environments (FrozenLake, CliffWalking, Taxi) and DummyEnv.
+//
+// The host compiles an env into a packed transition table
+//   entry[(state * (A + 1) + column) * O + outcome]
+//     bits  0..15  next state
+//     bits 16..23  index into the reward table that follows the entries
+//     bit  24      terminal (goal / hole / cliff / delivered)
+// with A the size of the Discrete action space, column A the "any other
+// action" case (Envs.FrozenLake.cs:56-62: a switch without default leaves the
+// state alone) and O = 3 outcomes for the slippery extension, else 1.  A
+// workgroup stages the table in LDS once and then grid-strides over the
+// batch, four envs per lane, so the per-step traffic is the SoA rows only.
+#include "gx_device.h"
+#include "gx_launch.h"
+
+namespace gx {
+
+__device__ __forceinline__ void load4i(const int32_t* base, uint64_t quad, int32_t (&out)[4]) {
+  int4 v = reinterpret_cast<const int4*>(base)[quad];
+  out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+}
+__device__ __forceinline__ void store4i(int32_t* base, uint64_t quad, const int32_t (&in)[4]) {
+  reinterpret_cast<int4*>(base)[quad] = make_int4(in[0], in[1], in[2], in[3]);
+}
+__device__ __forceinline__ void store4f(float* base, uint64_t quad, const float (&in)[4]) {
+  reinterpret_cast<float4*>(base)[quad] = make_float4(in[0], in[1], in[2], in[3]);
+}
+__device__ __forceinline__ uint32_t pack4(const bool (&b)[4]) {
+  return (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
+}
+
+// Reset state: FrozenLake 0 (Envs.FrozenLake.cs:47), CliffWalking 36
+// (Envs.CliffWalking.cs:31), Taxi `Next(500)` (Envs.Taxi.cs:20).
+__device__ __forceinline__ int32_t tabular_reset_state(int32_t start_state, const RngKey& key, uint64_t env) {
+  if (start_state >= 0) return start_state;
+  Draws d = philox_block(key, env, 0, 0);
+  if (start_state == -1) return d.below(0, 500);
+  // extension (upstream Taxi-v3): passenger neither in the taxi nor at the destination
+  int k = d.below(0, 300);
+  int cell = k / 12, rem = k % 12, pass = rem / 3, d3 = rem % 3;
+  int dest = d3 >= pass ? d3 + 1 : d3;
+  return (cell * 5 + pass) * 4 + dest;
+}
+
+template <int POLICY, bool LDS_TABLE>
+__global__ void __launch_bounds__(kBlock) tabular_step_kernel(StepArgs a) {
+  extern __shared__ uint32_t lds_table[];
+  const int A = a.table_actions, ncols = A + 1, O = a.table_outcomes;
+  const int entries = a.table_states * ncols * O;
+  const uint32_t* tab = a.table;
+  if (LDS_TABLE) {
+    for (int i = threadIdx.x; i < entries + 8; i += kBlock) lds_table[i] = a.table[i];
+    __syncthreads();
+    tab = lds_table;
+  }
+  const float* lut = reinterpret_cast<const float*>(tab + entries);
+
+  const bool autoreset = (a.flags & GX_AUTORESET) != 0;
+  const bool record = (a.flags & GX_RECORD_STATS) != 0;
+  int32_t* const state_row = a.state_int;
+  int32_t* const steps_row = a.state_int + a.stride;
+  StatAcc acc;
+
+  const uint64_t nquads = (a.num_envs + 3) >> 2;
+  for (uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q < nquads; q += (uint64_t)gridDim.x * kBlock) {
+    int32_t st[4], steps[4], ep_ret[4] = {}, ep_len[4] = {};
+    load4i(state_row, q, st);
+    load4i(steps_row, q, steps);
+    if (record) {
+      load4i(static_cast<const int32_t*>(a.ep_return), q, ep_ret);
+      if (a.ep_length) load4i(a.ep_length, q, ep_len);
+    }
+    float reward[4];
+    bool done[4], trunc[4];
+    for (int k = 0; k < a.k_steps; k++) {
+      const RngKey key = make_key(a.seed_lo, a.seed_hi, a.tick + (uint64_t)k);
+      int32_t act[4];
+      if (POLICY == GX_POLICY_DEVICE_ACTIONS)
+        load4i(static_cast<const int32_t*>(a.actions) + (uint64_t)k * a.action_stride, q, act);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint64_t env = a.env_index_base + q * 4 + j;
+        if (POLICY == GX_POLICY_RANDOM) act[j] = philox_block(key, env, 2, 0).below(0, A);
+        const int col = (uint32_t)act[j] < (uint32_t)A ? act[j] : A;
+        int o = 0;
+        if (O > 1 && col < A) o = philox_block(key, env, 1, 0).below(0, O);
+        // a state outside the table (only reachable through set_state) is clamped
+        const int s_in = (uint32_t)st[j] < (uint32_t)a.table_states ? st[j] : 0;
+        const uint32_t e = tab[(s_in * ncols + col) * O + o];
+        st[j] = (int32_t)(e & 0xFFFFu);
+        reward[j] = lut[(e >> 16) & 0x7u];
+        steps[j] += 1;
+        bool d = ((e >> 24) & 1u) != 0 || steps[j] >= a.step_limit;
+        bool t = a.time_limit > 0 && steps[j] >= a.time_limit;  // Wrappers.TimeLimit.cs:26-31
+        d = d || t;
+        done[j] = d;
+        trunc[j] = t;
+        if (record) {  // EnvWrapper.cs:46-55
+          ep_ret[j] += (int32_t)reward[j];
+          ep_len[j] += 1;
+          if (d) {
+            if (q * 4 + j < a.num_envs) acc.add((double)ep_ret[j], a.ep_length ? ep_len[j] : steps[j]);
+            ep_ret[j] = 0;
+            ep_len[j] = 0;
+          }
+        }
+        if (autoreset && d) {
+          st[j] = tabular_reset_state(a.start_state, key, env);
+          steps[j] = 0;
+        }
+      }
+    }
+    store4i(state_row, q, st);
+    store4i(steps_row, q, steps);
+    if (record) {
+      store4i(static_cast<int32_t*>(a.ep_return), q, ep_ret);
+      if (a.ep_length) store4i(a.ep_length, q, ep_len);
+    }
+    store4f(static_cast<float*>(a.reward), q, reward);
+    reinterpret_cast<uint32_t*>(a.done)[q] = pack4(done);
+    if (a.truncated) reinterpret_cast<uint32_t*>(a.truncated)[q] = pack4(trunc);
+  }
+  if (record) block_commit_stats(acc, a.stat_slots);
+}
+
+// DummyEnv.cs:23-30: state += action; reward = state; done = state >= 10.
+template <int POLICY>
+__global__ void __launch_bounds__(kBlock) dummy_step_kernel(StepArgs a) {
+  const bool autoreset = (a.flags & GX_AUTORESET) != 0;
+  const bool record = (a.flags & GX_RECORD_STATS) != 0;
+  int32_t* const state_row = a.state_int;
+  int32_t* const steps_row = a.state_int + a.stride;
+  StatAcc acc;
+  const uint64_t nquads = (a.num_envs + 3) >> 2;
+  for (uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q < nquads; q += (uint64_t)gridDim.x * kBlock) {
+    int32_t st[4], steps[4], ep_ret[4] = {}, ep_len[4] = {};
+    load4i(state_row, q, st);
+    load4i(steps_row, q, steps);
+    if (record) {
+      load4i(static_cast<const int32_t*>(a.ep_return), q, ep_ret);
+      if (a.ep_length) load4i(a.ep_length, q, ep_len);
+    }
+    float reward[4];
+    bool done[4], trunc[4];
+    for (int k = 0; k < a.k_steps; k++) {
+      const RngKey key = make_key(a.seed_lo, a.seed_hi, a.tick + (uint64_t)k);
+      int32_t act[4];
+      if (POLICY == GX_POLICY_DEVICE_ACTIONS)
+        load4i(static_cast<const int32_t*>(a.actions) + (uint64_t)k * a.action_stride, q, act);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint64_t env = a.env_index_base + q * 4 + j;
+        if (POLICY == GX_POLICY_RANDOM) act[j] = philox_block(key, env, 2, 0).below(0, 3);  // Discrete(3), DummyEnv.cs:14
+        st[j] += act[j];
+        steps[j] += 1;
+        reward[j] = (float)st[j];
+        bool d = st[j] >= 10;
+        bool t = a.time_limit > 0 && steps[j] >= a.time_limit;
+        d = d || t;
+        done[j] = d;
+        trunc[j] = t;
+        if (record) {
+          ep_ret[j] += st[j];
+          ep_len[j] += 1;
+          if (d) {
+            if (q * 4 + j < a.num_envs) acc.add((double)ep_ret[j], a.ep_length ? ep_len[j] : steps[j]);
+            ep_ret[j] = 0;
+            ep_len[j] = 0;
+          }
+        }
+        if (autoreset && d) {
+          st[j] = 0;  // DummyEnv.cs:17-21
+          steps[j] = 0;
+        }
+      }
+    }
+    store4i(state_row, q, st);
+    store4i(steps_row, q, steps);
+    if (record) {
+      store4i(static_cast<int32_t*>(a.ep_return), q, ep_ret);
+      if (a.ep_length) store4i(a.ep_length, q, ep_len);
+    }
+    store4f(static_cast<float*>(a.reward), q, reward);
+    reinterpret_cast<uint32_t*>(a.done)[q] = pack4(done);
+    if (a.truncated) reinterpret_cast<uint32_t*>(a.truncated)[q] = pack4(trunc);
+  }
+  if (record) block_commit_stats(acc, a.stat_slots);
+}
+
+__global__ void __launch_bounds__(kBlock) tabular_reset_kernel(StepArgs a) {
+  const RngKey key = make_key(a.seed_lo, a.seed_hi, a.tick);
+  const uint64_t nquads = (a.num_envs + 3) >> 2;
+  for (uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q < nquads; q += (uint64_t)gridDim.x * kBlock) {
+    int32_t st[4], zero[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 4; j++) st[j] = tabular_reset_state(a.start_state, key, a.env_index_base + q * 4 + j);
+    store4i(a.state_int, q, st);
+    store4i(a.state_int + a.stride, q, zero);
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) tabular_sample_kernel(StepArgs a, int32_t nact, int32_t* out) {
+  const RngKey key = make_key(a.seed_lo, a.seed_hi, a.tick);
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < a.num_envs; i += (uint64_t)gridDim.x * kBlock)
+    out[i] = philox_block(key, a.env_index_base + i, 2, 0).below(0, nact);
+}
+
+hipError_t launch_tabular_step(int env_id, const StepArgs& a, int policy, dim3 grid, size_t lds_bytes, hipStream_t stream) {
+  if (env_id == GX_ENV_DUMMY) {
+    if (policy == GX_POLICY_RANDOM)
+      hipLaunchKernelGGL(dummy_step_kernel<GX_POLICY_RANDOM>, grid, dim3(kBlock), 0, stream, a);
+    else
+      hipLaunchKernelGGL(dummy_step_kernel<GX_POLICY_DEVICE_ACTIONS>, grid, dim3(kBlock), 0, stream, a);
+    return hipGetLastError();
+  }
+  const bool lds = lds_bytes > 0;
+  if (policy == GX_POLICY_RANDOM) {
+    if (lds) hipLaunchKernelGGL((tabular_step_kernel<GX_POLICY_RANDOM, true>), grid, dim3(kBlock), lds_bytes, stream, a);
+    else hipLaunchKernelGGL((tabular_step_kernel<GX_POLICY_RANDOM, false>), grid, dim3(kBlock), 0, stream, a);
+  } else {
+    if (lds) hipLaunchKernelGGL((tabular_step_kernel<GX_POLICY_DEVICE_ACTIONS, true>), grid, dim3(kBlock), lds_bytes, stream, a);
+    else hipLaunchKernelGGL((tabular_step_kernel<GX_POLICY_DEVICE_ACTIONS, false>), grid, dim3(kBlock), 0, stream, a);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_tabular_reset(int env_id, const StepArgs& a, dim3 grid, hipStream_t stream) {
+  (void)env_id;
+  hipLaunchKernelGGL(tabular_reset_kernel, grid, dim3(kBlock), 0, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_tabular_sample(int env_id, const StepArgs& a, void* out, dim3 grid, hipStream_t stream) {
+  const int nact = env_id == GX_ENV_DUMMY ? 3 : a.table_actions;
+  hipLaunchKernelGGL(tabular_sample_kernel, grid, dim3(kBlock), 0, stream, a, nact, static_cast<int32_t*>(out));
+  return hipGetLastError();
+}
+
+}  // namespace gx

@@ -1,0 +1,163 @@
+"""Thin object layer over the C ABI: Context (one GPU) and DeviceBatch (one
+device-resident batch of environments).  Device buffers are exposed as torch
+tensors through the zero-copy view; torch is used for memory and streams only.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+_NP = {L.F32: np.float32, L.F64: np.float64, L.I32: np.int32, L.U8: np.uint8}
+
+
+class Context:
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        L.check(L.load().gx_ctx_create(device, C.byref(self._h)))
+        self.device = device
+
+    def synchronize(self):
+        L.check(L.load().gx_ctx_synchronize(self._h))
+
+    @property
+    def stream(self):
+        s = C.c_void_p()
+        L.check(L.load().gx_ctx_stream(self._h, C.byref(s)))
+        return s.value
+
+    def close(self):
+        if self._h:
+            L.load().gx_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class DeviceBatch:
+    """A batch of `num_envs` environments resident in HBM (VectorEnv.cs:10-35)."""
+
+    def __init__(self, ctx, env_id, num_envs, seed=0, flags=0, time_limit=0, mode=L.MODE_EXACT, map_rows=None,
+                 env_index_base=0):
+        lib = L.load()
+        self.ctx = ctx
+        rows = None
+        if map_rows is not None:
+            rows = map_rows.encode() if isinstance(map_rows, str) else "/".join(map_rows).encode()
+        d = L.GxDesc(C.sizeof(L.GxDesc), env_id, num_envs, seed, env_index_base, mode, flags, time_limit, 0, rows)
+        self._h = C.c_void_p()
+        L.check(lib.gx_vec_create(ctx._h, C.byref(d), C.byref(self._h)))
+        self.info = L.GxInfo()
+        L.check(lib.gx_vec_info(self._h, C.byref(self.info)))
+        self.n = num_envs
+        self.env_id = env_id
+        self.flags = flags
+        self.action_dtype = _NP[self.info.action_dtype]
+        self.reward_dtype = _NP[self.info.reward_dtype]
+        self.real_dtype = _NP[self.info.real_dtype]
+        self.obs_dtype = _NP[self.info.obs_dtype]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            L.load().gx_vec_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- control -------------------------------------------------------
+    @property
+    def tick(self):
+        t = C.c_uint64()
+        L.check(L.load().gx_vec_tick(self._h, C.byref(t)))
+        return t.value
+
+    def reset(self):
+        L.check(L.load().gx_vec_reset(self._h))
+
+    def get_state_raw(self):
+        buf = np.empty(self.info.state_bytes, np.uint8)
+        L.check(L.load().gx_vec_get_state(self._h, _ptr(buf), buf.size))
+        return buf
+
+    def set_state_raw(self, buf):
+        buf = np.ascontiguousarray(buf, np.uint8)
+        L.check(L.load().gx_vec_set_state(self._h, _ptr(buf), buf.size))
+
+    def split_state(self, buf):
+        nb = self.n * self.info.n_real * np.dtype(self.real_dtype).itemsize
+        reals = buf[:nb].view(self.real_dtype).reshape(self.info.n_real, self.n)
+        ints = buf[nb:].view(np.int32).reshape(self.info.n_int, self.n)
+        return reals, ints
+
+    def get_state(self):
+        return self.split_state(self.get_state_raw())
+
+    def set_state(self, reals, ints):
+        r = np.ascontiguousarray(reals, self.real_dtype).reshape(-1).view(np.uint8)
+        i = np.ascontiguousarray(ints, np.int32).reshape(-1).view(np.uint8)
+        self.set_state_raw(np.concatenate([r, i]))
+
+    def obs_shape(self):
+        if self.env_id == L.ENV_PONG:
+            return (self.n, self.info.obs_dim)
+        if self.info.obs_dtype == L.I32:
+            return (self.n,)
+        return (self.info.obs_dim, self.n)
+
+    def get_obs(self):
+        out = np.empty(self.obs_shape(), self.obs_dtype)
+        L.check(L.load().gx_vec_get_obs(self._h, _ptr(out), out.nbytes))
+        return out
+
+    # ---- host path -----------------------------------------------------
+    def step_host(self, actions, want_obs=False, want_trunc=False):
+        """VectorEnv.Step through pageable/pinned host buffers; returns numpy arrays."""
+        a = np.ascontiguousarray(actions, self.action_dtype)
+        if a.shape != (self.n,):
+            raise ValueError("actions must have shape (%d,)" % self.n)
+        reward = np.empty(self.n, self.reward_dtype)
+        done = np.empty(self.n, np.uint8)
+        trunc = np.empty(self.n, np.uint8) if want_trunc else None
+        obs = np.empty(self.obs_shape(), self.obs_dtype) if want_obs else None
+        lib = L.load()
+        L.check(lib.gx_vec_step_async(self._h, _ptr(a), _ptr(obs), _ptr(reward), _ptr(done), _ptr(trunc)))
+        L.check(lib.gx_vec_wait(self._h))
+        return obs, reward, done, trunc
+
+    def wait(self):
+        L.check(L.load().gx_vec_wait(self._h))
+
+    # ---- zero-copy path --------------------------------------------------
+    def step_device(self, d_actions_ptr, stream=None):
+        L.check(L.load().gx_vec_step_device(self._h, C.c_void_p(d_actions_ptr), C.c_void_p(stream or 0)))
+
+    def step_random(self, stream=None):
+        L.check(L.load().gx_vec_step_random(self._h, C.c_void_p(stream or 0)))
+
+    def rollout(self, k_steps, policy=L.POLICY_RANDOM, d_actions_ptr=None, stream=None):
+        L.check(L.load().gx_vec_rollout(self._h, k_steps, policy, C.c_void_p(d_actions_ptr or 0), C.c_void_p(stream or 0)))
+
+    def sample_actions(self, tick, d_actions_ptr, stream=None):
+        L.check(L.load().gx_vec_sample_actions(self._h, tick, C.c_void_p(d_actions_ptr), C.c_void_p(stream or 0)))
+
+    def view(self):
+        v = L.GxView()
+        L.check(L.load().gx_vec_device_view(self._h, C.byref(v)))
+        return v
+
+    def stats(self):
+        s = L.GxStats()
+        L.check(L.load().gx_vec_stats(self._h, C.byref(s)))
+        return s

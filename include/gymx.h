@@ -1,0 +1,226 @@
+/*
+ * gymx.h -- C ABI of the MI355X batched environment engine (libgymx.so).
+ *
+ * The reference (MCGPPeters/Gym, C#) has no native interface: its batched
+ * path is `VectorEnv<TState,TAction>` looping over `Env<,>.Step`
+ * (Gymnasium/VectorEnv.cs:10-35).  These entry points are what a C#
+ * `[LibraryImport]` binding for a device-resident replacement of that class
+ * calls; each one names the reference member it stands in for.
+ *
+ * Conventions
+ *  - every function returns a gx_status; nothing throws or aborts across the
+ *    boundary; gx_last_error() gives the thread-local message of the last
+ *    failure on the calling thread;
+ *  - handles are externally synchronised, like every object of the reference
+ *    (no locks anywhere in Gymnasium/); distinct handles may be driven from
+ *    distinct threads;
+ *  - the library owns all device memory behind a handle; device pointers
+ *    handed out by gx_vec_device_view stay valid until gx_vec_destroy;
+ *  - "SoA image" = component arrays one after another, each of num_envs
+ *    elements: first the n_real real-valued components (float, or double
+ *    when real_is_f64), then the n_int int32 components (the last one is the
+ *    per-env step counter).
+ */
+#ifndef GYMX_H
+#define GYMX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GX_VERSION 0x00010000u
+
+typedef enum gx_status {
+  GX_OK = 0,
+  GX_ERR_INVALID = 1,      /* bad argument / invalid action (the reference throws) */
+  GX_ERR_HIP = 2,          /* a HIP runtime call failed */
+  GX_ERR_OOM = 3,          /* device or host allocation failed */
+  GX_ERR_UNSUPPORTED = 4,  /* valid request this build cannot serve */
+  GX_ERR_RCCL = 5          /* an RCCL call failed */
+} gx_status;
+
+/* Environment ids: the registrations of GymnasiumRegistration.cs:10-28 that
+ * are on the device path, plus DummyEnv (DummyEnv.cs) for the reference's
+ * only known-answer test. */
+typedef enum gx_env_id {
+  GX_ENV_CARTPOLE = 0,         /* "CartPole-v1"              Envs.CartPole.cs */
+  GX_ENV_MOUNTAINCAR = 1,      /* "MountainCar-v0"           Envs.MountainCar.cs */
+  GX_ENV_MOUNTAINCAR_CONT = 2, /* "MountainCarContinuous-v0" Envs.MountainCarContinuous.cs */
+  GX_ENV_PENDULUM = 3,         /* "Pendulum-v1"              Envs.Pendulum.cs */
+  GX_ENV_ACROBOT = 4,          /* "Acrobot-v1"               Envs.Acrobot.cs */
+  GX_ENV_FROZENLAKE = 5,       /* "FrozenLake-v1"            Envs.FrozenLake.cs */
+  GX_ENV_TAXI = 6,             /* "Taxi-v3"                  Envs.Taxi.cs */
+  GX_ENV_CLIFFWALKING = 7,     /* "CliffWalking-v0"          Envs.CliffWalking.cs */
+  GX_ENV_PONG = 8,             /* "Pong-v4"                  Envs.Pong.cs */
+  GX_ENV_DUMMY = 9,            /* DummyEnv.cs */
+  GX_ENV_COUNT = 10
+} gx_env_id;
+
+/* Numeric mode of the continuous-control kernels. */
+typedef enum gx_mode {
+  GX_MODE_EXACT = 0,  /* operation-for-operation binary32 as the C# source; sin/cos/atan2 in
+                         binary64 rounded once, no contraction (default) */
+  GX_MODE_FAST32 = 1  /* binary32 device trig, fused multiply-add allowed */
+} gx_mode;
+
+typedef enum gx_flags {
+  GX_AUTORESET = 1u,    /* Reset() an env in the same step that returns done (the reference's
+                           VectorEnv.Step, VectorEnv.cs:28-34, never resets; default off) */
+  GX_RECORD_STATS = 2u, /* fuse RecordEpisodeStatistics (EnvWrapper.cs:23-58) into the step */
+  GX_SLIPPERY = 4u,     /* extension: upstream FrozenLake is_slippery (the reference is deterministic) */
+  GX_TAXI_FULL = 8u,    /* extension: upstream Taxi-v3 transitions (the reference is a stub) */
+  GX_ACROBOT_RK4 = 16u  /* extension: upstream Acrobot, classical RK4 in binary64
+                           (the reference integrates with semi-implicit Euler in binary32) */
+} gx_flags;
+
+typedef enum gx_policy {
+  GX_POLICY_DEVICE_ACTIONS = 0, /* actions read from a device array */
+  GX_POLICY_RANDOM = 1          /* ActionSpace.Sample() per env per step from the counter RNG
+                                   (Spaces.Discrete.cs:18, Spaces.Box.cs:25-33) */
+} gx_policy;
+
+typedef enum gx_dtype { GX_F32 = 0, GX_F64 = 1, GX_I32 = 2, GX_U8 = 3 } gx_dtype;
+
+typedef struct gx_ctx gx_ctx;
+typedef struct gx_vec gx_vec;
+typedef struct gx_comm gx_comm;
+
+/* Construction parameters of a batch (the reference has no configuration
+ * beyond constructor arguments: Envs.FrozenLake.cs:23 map, TimeLimit maxSteps
+ * Wrappers.TimeLimit.cs:11). */
+typedef struct gx_desc {
+  uint32_t struct_size;    /* sizeof(gx_desc), for forward compatibility */
+  int32_t env_id;          /* gx_env_id */
+  uint64_t num_envs;       /* VectorEnv.NumEnvs, VectorEnv.cs:13 */
+  uint64_t seed;           /* key of the per-env counter RNG */
+  uint64_t env_index_base; /* global index of env 0: RNG streams are keyed by the global
+                              index so results do not depend on how a batch is sharded */
+  int32_t mode;            /* gx_mode */
+  uint32_t flags;          /* gx_flags */
+  int32_t time_limit;      /* TimeLimit maxSteps (Wrappers.TimeLimit.cs:8); 0 = no wrapper */
+  int32_t reserved;
+  const char* map_rows;    /* FrozenLake rows joined by '/', NULL = default 4x4 map
+                              (Envs.FrozenLake.cs:25-30), "8x8" = upstream's 8x8 map */
+} gx_desc;
+
+/* Static facts about a batch (what an agent reads from ActionSpace /
+ * ObservationSpace, e.g. Envs.CartPole.cs:12-16). */
+typedef struct gx_info {
+  uint64_t num_envs;
+  int32_t env_id;
+  int32_t n_real;          /* real-valued state components */
+  int32_t real_dtype;      /* GX_F32 or GX_F64 */
+  int32_t n_int;           /* int32 state components, the last is the step counter */
+  int32_t obs_dim;         /* elements per env in the observation */
+  int32_t obs_dtype;       /* GX_F32 (classic control), GX_I32 (tabular), GX_U8 (Pong) */
+  int32_t action_dtype;    /* GX_I32 (Discrete) or GX_F32 (Box of dimension 1) */
+  int32_t action_n;        /* Discrete.N, or 0 for Box */
+  float action_low, action_high; /* Box bounds when action_dtype == GX_F32 */
+  int32_t reward_dtype;    /* GX_F32, or GX_F64 where the reference computes a double */
+  int32_t obs_is_state;    /* 1: the observation is the real state image itself */
+  uint64_t state_bytes;    /* size of the SoA image for get/set_state */
+  uint64_t obs_bytes;      /* size of a host observation buffer */
+} gx_info;
+
+/* Device pointers for on-GPU agents (zero-copy path). */
+typedef struct gx_view {
+  uint64_t num_envs;
+  uint64_t stride;    /* elements between consecutive component arrays (>= num_envs) */
+  void* state_real;   /* [n_real][stride] float or double */
+  int32_t* state_int; /* [n_int][stride] */
+  void* obs;          /* classic: == state_real (or float [obs_dim][stride] when it is derived);
+                         tabular: == state_int; Pong: uint8 [num_envs][100800] */
+  void* reward;       /* [num_envs] float or double (gx_info.reward_dtype) */
+  uint8_t* done;      /* [num_envs] */
+  uint8_t* truncated; /* [num_envs], NULL unless time_limit > 0 */
+} gx_view;
+
+/* Aggregate of RecordEpisodeStatistics.EpisodeRewards / EpisodeLengths
+ * (EnvWrapper.cs:25-26) over all envs of a batch. */
+typedef struct gx_stats {
+  int64_t episodes;
+  double sum_return;
+  int64_t sum_length;
+  double sum_return_sq;
+  double min_return; /* +inf when episodes == 0 */
+  double max_return; /* -inf when episodes == 0 */
+} gx_stats;
+
+/* ---- library ---------------------------------------------------------- */
+uint32_t gx_version(void);
+const char* gx_last_error(void);
+int gx_device_count(int* count);
+
+/* ---- context: one per GPU -------------------------------------------- */
+int gx_ctx_create(int device, gx_ctx** out);
+int gx_ctx_destroy(gx_ctx* ctx);
+int gx_ctx_synchronize(gx_ctx* ctx);
+/* The HIP stream (hipStream_t) step kernels are launched on when the caller
+ * passes no stream of its own. */
+int gx_ctx_stream(gx_ctx* ctx, void** stream);
+
+/* ---- batch: replaces `new VectorEnv<,>(List<Env<,>>)`, VectorEnv.cs:15 -- */
+int gx_vec_create(gx_ctx* ctx, const gx_desc* desc, gx_vec** out);
+int gx_vec_destroy(gx_vec* vec); /* Env.Close(), Env.cs:28 */
+int gx_vec_info(const gx_vec* vec, gx_info* out);
+
+/* VectorEnv.Reset(), VectorEnv.cs:20-26 (through RecordEpisodeStatistics.Reset
+ * EnvWrapper.cs:32-42 and TimeLimit.Reset Wrappers.TimeLimit.cs:17-21 when fused). */
+int gx_vec_reset(gx_vec* vec);
+
+/* The reference keeps state private and has no setter; these exist for the
+ * replay harness and double as checkpoint/resume.  Synchronous. */
+int gx_vec_get_state(gx_vec* vec, void* host_soa, size_t bytes);
+int gx_vec_set_state(gx_vec* vec, const void* host_soa, size_t bytes);
+/* Observation of every env as Reset()/Step() would return it: classic control
+ * float[obs_dim][num_envs]; tabular int32[num_envs]; Pong uint8[num_envs][100800].
+ * Synchronous. */
+int gx_vec_get_obs(gx_vec* vec, void* host_obs, size_t bytes);
+
+/* VectorEnv.Step(List<TAction>), VectorEnv.cs:28-34 -- host path.  h_actions is
+ * int32[num_envs] or float[num_envs].  Output pointers may be NULL (that copy
+ * is skipped).  Buffers are caller-owned, should be pinned, and must stay
+ * alive and untouched until gx_vec_wait returns.  Copies run on a side stream
+ * ordered against the compute stream by events. */
+int gx_vec_step_async(gx_vec* vec, const void* h_actions, void* h_obs, void* h_reward, uint8_t* h_done,
+                      uint8_t* h_truncated);
+int gx_vec_wait(gx_vec* vec);
+
+/* VectorEnv.Step -- zero-copy path: actions already on the device, results
+ * read through gx_vec_device_view.  `stream` is a hipStream_t or NULL for the
+ * context's stream; the call only enqueues. */
+int gx_vec_step_device(gx_vec* vec, const void* d_actions, void* stream);
+/* One step with actions sampled on the device (GX_POLICY_RANDOM). */
+int gx_vec_step_random(gx_vec* vec, void* stream);
+int gx_vec_device_view(gx_vec* vec, gx_view* out);
+
+/* K fused steps with the state held in registers.  policy RANDOM samples
+ * actions in the kernel; DEVICE_ACTIONS reads d_actions[K][stride].  The
+ * reward/done/truncated arrays of the view hold the last step's values. */
+int gx_vec_rollout(gx_vec* vec, int k_steps, int policy, const void* d_actions, void* stream);
+
+/* Draws of the random policy for one tick, written to a device array
+ * (int32 or float [num_envs]); for harnesses that replay the same actions
+ * through another engine. */
+int gx_vec_sample_actions(gx_vec* vec, uint64_t tick, void* d_actions, void* stream);
+int gx_vec_tick(const gx_vec* vec, uint64_t* tick);
+
+/* RecordEpisodeStatistics aggregate of this batch (device reduction + copy). */
+int gx_vec_stats(gx_vec* vec, gx_stats* out);
+
+/* ---- multi-GPU: episode statistics only -------------------------------- */
+/* unique_id: 128 bytes, produced by rank 0 with gx_comm_unique_id and passed
+ * to the other ranks by the host program. */
+int gx_comm_unique_id(void* id128);
+int gx_comm_init(gx_ctx* ctx, const void* id128, int rank, int world, gx_comm** out);
+int gx_comm_destroy(gx_comm* comm);
+/* All-reduce (sum / min / max per field) of the batch's statistics over RCCL. */
+int gx_stats_allreduce(gx_comm* comm, gx_vec* vec, gx_stats* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GYMX_H */

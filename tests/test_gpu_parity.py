@@ -1,0 +1,308 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the
+same seeded inputs.  Bit-exact for integer/byte work (tabular envs, Pong game
+state and frames, counters, flags); for continuous dynamics the bar is
+relative error <= 1e-5 per step with the device state re-synchronised to the
+oracle's after any step that differs (teacher forcing), and in practice the
+results are bit-identical except where the device's binary64 sin/cos/atan2
+and glibc's differ in the last place AND that flips the float rounding.
+"""
+import numpy as np
+import pytest
+
+from gpu_common import L, bits, make_pair, random_actions, ulp_mismatch
+
+pytestmark = pytest.mark.gpu
+
+CLASSIC = [L.ENV_CARTPOLE, L.ENV_MOUNTAINCAR, L.ENV_MOUNTAINCAR_CONT, L.ENV_PENDULUM, L.ENV_ACROBOT]
+TABULAR = [L.ENV_FROZENLAKE, L.ENV_TAXI, L.ENV_CLIFFWALKING, L.ENV_DUMMY]
+REL_TOL = 1e-5           # stated tolerance for continuous dynamics, binary32
+MAX_MISMATCH_FRAC = 1e-5  # fraction of elements allowed to differ in the last place
+
+
+def compare_step(g, o, a, t, exact):
+    """one host-path step on both engines; returns number of state elements that differ"""
+    obs, rew, done, _ = g.step_host(a)
+    orew, odone, _ = o.step(a)
+    gr, gi = g.get_state()
+    orr, oi = o.get_state()
+    assert np.array_equal(gi, oi), "int state differs at step %d" % t
+    if exact:
+        assert np.array_equal(bits(gr), bits(orr)), "state differs at step %d" % t
+        assert np.array_equal(rew.astype(np.float64), orew), "reward differs at step %d" % t
+        assert np.array_equal(done, odone), "done differs at step %d" % t
+        return 0
+    n, rel = ulp_mismatch(gr, orr)
+    assert rel <= REL_TOL, "state relative error %g at step %d" % (rel, t)
+    nr, relr = ulp_mismatch(rew.astype(np.float64), orew)
+    assert relr <= REL_TOL
+    if n == 0:
+        assert np.array_equal(done, odone)
+    else:
+        g.set_state(orr, oi)  # teacher forcing
+    return n
+
+
+@pytest.mark.parametrize("env_id", CLASSIC + TABULAR + [L.ENV_PONG])
+def test_reset_matches_oracle(oracle, env_id):
+    g, o = make_pair(oracle, env_id, 1000, seed=77, base=5)
+    g.reset(); o.reset()
+    gr, gi = g.get_state(); orr, oi = o.get_state()
+    assert np.array_equal(bits(gr), bits(orr)) and np.array_equal(gi, oi)
+    g.reset(); o.reset()  # second reset uses a new tick, hence new draws
+    gr2, _ = g.get_state(); orr2, _ = o.get_state()
+    assert np.array_equal(bits(gr2), bits(orr2))
+    if gr.size and env_id not in (L.ENV_PONG,):
+        assert not np.array_equal(gr, gr2)
+    assert np.array_equal(bits(g.get_obs()), bits(o.get_obs()))
+
+
+@pytest.mark.parametrize("env_id", CLASSIC)
+def test_classic_free_run(oracle, env_id):
+    n, steps = 4099, 96  # ragged: not a multiple of the 4-env lane width
+    g, o = make_pair(oracle, env_id, n, seed=11)
+    g.reset(); o.reset()
+    rng = np.random.default_rng(env_id)
+    bad = 0
+    for t in range(steps):
+        bad += compare_step(g, o, random_actions(rng, env_id, n), t, exact=False)
+    total = n * g.info.n_real * steps
+    assert bad <= max(2, MAX_MISMATCH_FRAC * total), "%d of %d elements differ" % (bad, total)
+
+
+@pytest.mark.parametrize("env_id", CLASSIC)
+def test_classic_wide_states(oracle, env_id):
+    """states far outside the reset range: large angles, saturated velocities, step counters near the limit"""
+    n = 8192
+    g, o = make_pair(oracle, env_id, n, seed=3)
+    g.reset(); o.reset()
+    rng = np.random.default_rng(100 + env_id)
+    dim = g.info.n_real
+    scale = np.array([3, 3, 50, 20, 20, 20][:dim])[:, None]
+    s = (rng.standard_normal((dim, n)) * scale).astype(np.float32)
+    st = rng.integers(0, 600, (1, n)).astype(np.int32)
+    g.set_state(s, st); o.set_state(s, st)
+    bad = compare_step(g, o, random_actions(rng, env_id, n), 0, exact=False)
+    assert bad <= 2
+
+
+@pytest.mark.parametrize("env_id", TABULAR)
+def test_tabular_bit_exact(oracle, env_id):
+    n, steps = 4099, 230
+    g, o = make_pair(oracle, env_id, n, seed=5)
+    g.reset(); o.reset()
+    rng = np.random.default_rng(env_id)
+    for t in range(steps):
+        compare_step(g, o, random_actions(rng, env_id, n, wide=True), t, exact=True)
+        assert np.array_equal(g.get_obs(), o.get_obs())
+
+
+@pytest.mark.parametrize("rows", ["8x8", ["SFG", "HFF"], ["SFFFH", "FFHFF", "FFFFG"]])
+def test_frozenlake_maps(oracle, rows):
+    n = 1024
+    g, o = make_pair(oracle, L.ENV_FROZENLAKE, n, map_rows=rows)
+    g.reset(); o.reset()
+    rng = np.random.default_rng(9)
+    for t in range(120):
+        compare_step(g, o, random_actions(rng, L.ENV_FROZENLAKE, n, wide=True), t, exact=True)
+
+
+def test_frozenlake_slippery_and_taxi_full_extensions(oracle):
+    """extensions (not in the reference): pinned by the oracle's own definition only"""
+    n = 4096
+    for env_id, flags, rows in [(L.ENV_FROZENLAKE, L.SLIPPERY, "8x8"), (L.ENV_TAXI, L.TAXI_FULL, None)]:
+        g, o = make_pair(oracle, env_id, n, seed=21, flags=flags | L.AUTORESET, map_rows=rows)
+        g.reset(); o.reset()
+        rng = np.random.default_rng(2)
+        for t in range(150):
+            compare_step(g, o, random_actions(rng, env_id, n), t, exact=True)
+
+
+def test_dummy_env_reference_kat_through_abi():
+    """Gymnasium.Tests/DummyEnvTests.cs:6-21, through libgymx.so on the GPU."""
+    from gym_amd.engine import DeviceBatch
+    from gpu_common import ctx
+    g = DeviceBatch(ctx(), L.ENV_DUMMY, 1)
+    g.reset()
+    assert g.get_obs()[0] == 0
+    _, r, d, _ = g.step_host([1])
+    assert g.get_obs()[0] == 1 and r[0] == 1.0 and not d[0]
+    for _ in range(9):
+        _, r, d, _ = g.step_host([1])
+    assert d[0]
+
+
+def test_hand_derived_paths_through_abi():
+    from gym_amd.engine import DeviceBatch
+    from gpu_common import ctx
+    g = DeviceBatch(ctx(), L.ENV_FROZENLAKE, 1)
+    g.reset()
+    states, rewards, dones = [], [], []
+    for a in [1, 1, 2, 1, 2, 2]:  # Envs.FrozenLake.cs:52-69 on the default map
+        _, r, d, _ = g.step_host([a])
+        states.append(int(g.get_obs()[0])); rewards.append(float(r[0])); dones.append(bool(d[0]))
+    assert states == [4, 8, 9, 13, 14, 15] and rewards == [0, 0, 0, 0, 0, 1] and dones == [False] * 5 + [True]
+    c = DeviceBatch(ctx(), L.ENV_CLIFFWALKING, 1)
+    c.reset()
+    out = []
+    for a in [3] + [2] * 11 + [1]:  # Envs.CliffWalking.cs:36-54
+        _, r, d, _ = c.step_host([a])
+        out.append((int(c.get_obs()[0]), float(r[0]), bool(d[0])))
+    assert [s for s, _, _ in out] == [24] + list(range(25, 36)) + [47]
+    assert [r for _, r, _ in out] == [-1.0] * 12 + [0.0] and [d for _, _, d in out] == [False] * 12 + [True]
+    c.reset()
+    _, r, d, _ = c.step_host([2])
+    assert c.get_obs()[0] == 37 and r[0] == -100.0 and d[0]
+    t = DeviceBatch(ctx(), L.ENV_TAXI, 2, seed=4)
+    t.reset()
+    s0 = t.get_obs().copy()
+    for k in range(200):  # Envs.Taxi.cs:25-33
+        _, r, d, _ = t.step_host([k % 6, 5])
+        assert (r == -1.0).all() and (t.get_obs() == s0).all() and d.all() == (k == 199)
+
+
+def test_pong_state_and_frames_bit_exact(oracle):
+    n, steps = 257, 600
+    g, o = make_pair(oracle, L.ENV_PONG, n, seed=8)
+    assert np.array_equal(g.get_obs(), o.get_obs())  # the constructor resets (Envs.Pong.cs:47-52)
+    g.reset(); o.reset()
+    assert np.array_equal(g.get_obs(), o.get_obs())
+    rng = np.random.default_rng(4)
+    scored = 0
+    for t in range(steps):
+        a = random_actions(rng, L.ENV_PONG, n, wide=True)
+        obs, rew, done, _ = g.step_host(a, want_obs=(t % 50 == 0))
+        orew, odone, _ = o.step(a)
+        assert np.array_equal(rew.astype(np.float64), orew) and np.array_equal(done, odone)
+        scored += int((orew != 0).sum())
+        if obs is not None:
+            assert np.array_equal(obs, o.get_obs()), "frames differ at step %d" % t
+    gr, gi = g.get_state(); orr, oi = o.get_state()
+    assert np.array_equal(bits(gr), bits(orr)) and np.array_equal(gi, oi)
+    assert scored > 0
+    assert np.array_equal(g.get_obs(), o.get_obs())
+
+
+def test_pong_frames_edge_states(oracle):
+    """ball in every corner, paddles at both ends, one-, two- and many-digit scores"""
+    cases = np.array([
+        [160.0, 208.0, 3, 1, 0.0, 195.0, 21, 9, 5], [0.0, 0.0, -3, -1, 195.0, 0.0, 10, 123, 7],
+        [159.2, 104.9, 3, 0, 3.2, 190.8, 0, 21, 1], [79.5, 19.5, 3, 0, 97.5, 97.5, 7, 8, 2],
+        [38.0, 21.0, -3, 2, 50.0, 60.0, 4, 1234567, 3], [118.0, 23.9, 3, 2, 0.4, 194.9, 2147483647, 99, 0],
+    ])
+    n = len(cases)
+    g, o = make_pair(oracle, L.ENV_PONG, n)
+    reals = cases[:, :6].T.copy()
+    ints = cases[:, 6:].T.astype(np.int32).copy()
+    g.set_state(reals, ints); o.set_state(reals, ints)
+    assert np.array_equal(g.get_obs(), o.get_obs())
+
+
+@pytest.mark.parametrize("env_id", [L.ENV_CARTPOLE, L.ENV_PENDULUM, L.ENV_CLIFFWALKING, L.ENV_PONG, L.ENV_DUMMY])
+@pytest.mark.parametrize("flags,time_limit", [(L.AUTORESET | L.RECORD_STATS, 0), (L.RECORD_STATS, 17), (L.AUTORESET | L.RECORD_STATS, 9), (L.AUTORESET, 0)])
+def test_fused_wrappers(oracle, env_id, flags, time_limit):
+    """auto-reset, TimeLimit (Wrappers.TimeLimit.cs) and RecordEpisodeStatistics (EnvWrapper.cs:23-58) fused in the step"""
+    n, steps = 1027, 70
+    g, o = make_pair(oracle, env_id, n, seed=13, flags=flags, time_limit=time_limit, base=1 << 33)
+    g.reset(); o.reset()
+    rng = np.random.default_rng(6)
+    exact = env_id in (L.ENV_CLIFFWALKING, L.ENV_PONG, L.ENV_DUMMY)
+    for t in range(steps):
+        a = random_actions(rng, env_id, n)
+        obs, rew, done, trunc = g.step_host(a, want_trunc=time_limit > 0)
+        orew, odone, otrunc = o.step(a)
+        gr, gi = g.get_state(); orr, oi = o.get_state()
+        assert np.array_equal(gi, oi) and np.array_equal(done, odone)
+        if time_limit > 0:
+            assert np.array_equal(trunc, otrunc)
+        if exact:
+            assert np.array_equal(bits(gr), bits(orr)) and np.array_equal(rew.astype(np.float64), orew)
+        else:
+            cnt, rel = ulp_mismatch(gr, orr)
+            assert cnt == 0, "state mismatch (%d elements, rel %g) at step %d" % (cnt, rel, t)
+        if t == 40:
+            g.reset(); o.reset()  # EnvWrapper.cs:34-38: open episodes are recorded by Reset()
+    if flags & L.RECORD_STATS:
+        gs, os_ = g.stats(), o.stats()
+        assert gs.episodes == os_.episodes and gs.sum_length == os_.sum_length
+        assert gs.episodes > 0
+        if env_id == L.ENV_PENDULUM:
+            assert abs(gs.sum_return - os_.sum_return) <= 1e-9 * abs(os_.sum_return)
+            assert abs(gs.min_return - os_.min_return) <= 1e-9 * abs(os_.min_return)
+        else:
+            assert gs.sum_return == os_.sum_return and gs.sum_return_sq == os_.sum_return_sq
+            assert gs.min_return == os_.min_return and gs.max_return == os_.max_return
+
+
+@pytest.mark.parametrize("env_id", CLASSIC + [L.ENV_FROZENLAKE, L.ENV_TAXI, L.ENV_PONG])
+def test_random_policy_and_rollout(oracle, env_id):
+    """actions sampled on the device (Spaces.Discrete.cs:18 / Spaces.Box.cs:25-33) and K fused steps"""
+    n, k = 2051, 24
+    flags = L.AUTORESET | L.RECORD_STATS
+    g, o = make_pair(oracle, env_id, n, seed=99, flags=flags)
+    g2, _ = make_pair(oracle, env_id, n, seed=99, flags=flags)
+    g.reset(); o.reset(); g2.reset()
+    for t in range(k):
+        g.step_random()
+        o.step_random()
+    g2.rollout(k)
+    g.ctx.synchronize()
+    gr, gi = g.get_state(); g2r, g2i = g2.get_state(); orr, oi = o.get_state()
+    # K single steps and one K-step rollout are the same computation
+    assert np.array_equal(bits(gr), bits(g2r)) and np.array_equal(gi, g2i)
+    s1, s2, so = g.stats(), g2.stats(), o.stats()
+    assert s1.episodes == s2.episodes and s1.sum_length == s2.sum_length
+    if env_id in (L.ENV_FROZENLAKE, L.ENV_TAXI, L.ENV_PONG):
+        assert np.array_equal(bits(gr), bits(orr)) and np.array_equal(gi, oi)
+        assert s1.episodes == so.episodes and s1.sum_return == so.sum_return and s1.sum_length == so.sum_length
+    else:
+        # free-running chaotic dynamics: compare only while no last-place event occurred
+        cnt, rel = ulp_mismatch(gr, orr)
+        assert cnt <= 8, "%d elements differ (rel %g)" % (cnt, rel)
+        if cnt == 0:
+            assert np.array_equal(gi, oi) and s1.episodes == so.episodes and s1.sum_length == so.sum_length
+
+
+def test_acrobot_invalid_action_is_an_error(oracle):
+    """Envs.Acrobot.cs:45,51 throws IndexOutOfRangeException; the ABI returns GX_ERR_INVALID"""
+    from gym_amd._lib import GymxError
+    g, _ = make_pair(oracle, L.ENV_ACROBOT, 8)
+    g.reset()
+    with pytest.raises(GymxError) as e:
+        g.step_host(np.array([0, 1, 2, 3, 0, 0, 0, 0], np.int32))
+    assert e.value.code == L.GX_ERR_INVALID
+
+
+def test_fast32_mode_within_tolerance(oracle):
+    n = 4096
+    for env_id in CLASSIC:
+        g, o = make_pair(oracle, env_id, n, seed=31, mode=L.MODE_FAST32)
+        g.reset(); o.reset()
+        rng = np.random.default_rng(env_id)
+        for t in range(30):
+            a = random_actions(rng, env_id, n)
+            g.step_host(a); o.step(a)
+            gr, gi = g.get_state(); orr, oi = o.get_state()
+            err = np.abs(gr.astype(np.float64) - orr) / np.maximum(np.abs(orr), 1e-3)
+            assert err.max() <= 1e-5, (env_id, t, err.max())
+            g.set_state(orr, oi)  # teacher forcing per step
+
+
+def test_acrobot_rk4_fp64_extension(oracle):
+    """extension, pinned only by the oracle's own restatement: relative 1e-9 per step, teacher-forced"""
+    n = 4096
+    g, o = make_pair(oracle, L.ENV_ACROBOT, n, seed=17, flags=L.ACROBOT_RK4)
+    g.reset(); o.reset()
+    gr, gi = g.get_state(); orr, oi = o.get_state()
+    assert np.array_equal(bits(gr), bits(orr))
+    rng = np.random.default_rng(3)
+    for t in range(40):
+        a = random_actions(rng, L.ENV_ACROBOT, n)
+        _, rew, done, _ = g.step_host(a)
+        orew, odone, _ = o.step(a)
+        gr, gi = g.get_state(); orr, oi = o.get_state()
+        err = np.abs(gr - orr) / np.maximum(np.abs(orr), 1e-6)
+        assert err.max() <= 1e-9, (t, err.max())
+        assert np.array_equal(gi, oi)
+        gobs, oobs = g.get_obs(), o.get_obs()
+        assert np.abs(gobs - oobs).max() <= 1e-6
+        g.set_state(orr, oi)
