@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/sec of the batched step path on MI355X.
+
+One "step" = one VectorEnv.Step over the whole batch: CartPole-v1, 16 Mi
+envs per GPU, single-step kernel with auto-reset and RecordEpisodeStatistics
+fused, actions read from a device-resident array (zero-copy path), EXACT
+numeric mode.  State, actions and outputs are resident in HBM before the
+timed region starts.
+
+  python bench.py --gpus 1 --steps 200 --warmup 20
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints one JSON line.  The batch is sharded by env index (RNG streams
+are keyed by the global index); there is no collective in the step path, and
+episode statistics are all-reduced once over RCCL after the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402  (device memory, streams, events, torch.distributed only)
+
+from gym_amd import _lib as L  # noqa: E402
+from gym_amd.engine import Context, DeviceBatch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0       # MI355X HBM3E peak
+FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X vector FP64 peak
+
+# algorithmic bytes per env-step, single-step mode with auto-reset and
+# statistics fused: each logical array counted once per read and once per
+# write at its stored width
+B_ALG = {
+    # state r+w, action r, steps r+w, ep_return r+w, reward w, done w
+    "cartpole": 16 + 16 + 4 + 4 + 4 + 4 + 4 + 4 + 1,       # 57
+    "mountaincar": 8 + 8 + 4 + 4 + 4 + 4 + 4 + 4 + 1,      # 41
+    "acrobot": 24 + 24 + 4 + 4 + 4 + 4 + 4 + 4 + 1,        # 73
+    "pendulum": 12 + 12 + 4 + 4 + 4 + 8 + 8 + 8 + 1,       # 61: reward and ep_return are binary64
+    "frozenlake": 4 + 4 + 4 + 4 + 4 + 4 + 4 + 4 + 1,       # 33
+    "pong": 60 + 60 + 4 + 4 + 4 + 4 + 1 + 100800,          # 100937
+}
+ENV_IDS = {"cartpole": L.ENV_CARTPOLE, "mountaincar": L.ENV_MOUNTAINCAR, "acrobot": L.ENV_ACROBOT,
+           "pendulum": L.ENV_PENDULUM, "frozenlake": L.ENV_FROZENLAKE, "pong": L.ENV_PONG}
+# FP64 operations per env-step of the RK4 Acrobot (4 derivative evaluations of
+# ~32 flops, 52 for the RK4 combination, ~16 for wrap/clamp/termination),
+# transcendentals not counted
+ACROBOT_RK4_FLOPS = 196
+
+
+def time_steps(batch, step_fn, steps, warmup, dist):
+    """W untimed + K timed steps; returns (wall seconds max over ranks, mean kernel ms from HIP events)"""
+    stream = torch.cuda.current_stream()
+    for _ in range(warmup):
+        step_fn()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(steps):
+        step_fn()
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / steps
+    if dist is not None:
+        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    return wall, kernel_ms
+
+
+def cpu_baseline(env_name, target_seconds=12.0):
+    """The oracle arranged like the reference's VectorEnv (heap objects, virtual Step,
+    one sequential loop, VectorEnv.cs:28-34) timed on one host core, on a bounded sample."""
+    from oracle import oracle as O
+
+    eid = {"cartpole": O.CARTPOLE, "acrobot": O.ACROBOT, "mountaincar": O.MOUNTAINCAR, "pendulum": O.PENDULUM,
+           "frozenlake": O.FROZENLAKE, "pong": O.PONG}[env_name]
+    n = 1024 if env_name == "pong" else 1 << 16
+    secs, steps_done = O.bench_reference_shaped(eid, n, 8 if env_name == "pong" else 16)
+    rate = steps_done / max(secs, 1e-9)
+    k = max(8, int(target_seconds * rate / n))
+    secs, steps_done = O.bench_reference_shaped(eid, n, k)
+    return {
+        "value": steps_done / secs, "unit": "env-steps/s", "cores": 1, "kind": "port",
+        "sample": "%s, %d envs x %d batched steps, random actions, reset on done; C restatement shaped like the "
+                  "reference VectorEnv loop (no per-step Dictionary/boxing, so it flatters the C# reference)" % (env_name, n, k),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--env", default="cartpole", choices=sorted(ENV_IDS))
+    ap.add_argument("--num-envs", type=int, default=0, help="envs per GPU (default 16 Mi; Pong 65536)")
+    ap.add_argument("--policy", default="device", choices=["device", "random"])
+    ap.add_argument("--mode", default="exact", choices=["exact", "fast32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary Acrobot measurements")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist_mod.init_process_group("nccl", rank=rank, world_size=world)
+        dist = dist_mod
+    else:
+        torch.cuda.set_device(0)
+    if world != args.gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+
+    n = args.num_envs or (65536 if args.env == "pong" else 1 << 24)
+    # a non-default torch stream: kernels are launched on it through the C ABI's stream
+    # argument and the HIP events that time them are recorded on the same stream
+    torch.cuda.set_stream(torch.cuda.Stream())
+    ctx = Context(local_rank)
+    flags = L.AUTORESET | L.RECORD_STATS
+    mode = L.MODE_EXACT if args.mode == "exact" else L.MODE_FAST32
+    batch = DeviceBatch(ctx, ENV_IDS[args.env], n, seed=0x9E3779B97F4A7C15, flags=flags, mode=mode,
+                        env_index_base=rank * n)
+    batch.reset()
+    stream_ptr = torch.cuda.current_stream().cuda_stream
+    view = batch.view()
+    if args.policy == "device":
+        adt = torch.float32 if batch.info.action_dtype == L.F32 else torch.int32
+        actions = torch.empty(int(view.stride), dtype=adt, device="cuda")
+        batch.sample_actions(0, actions.data_ptr(), stream_ptr)
+        step_fn = lambda: batch.step_device(actions.data_ptr(), stream_ptr)  # noqa: E731
+    else:
+        step_fn = lambda: batch.step_random(stream_ptr)  # noqa: E731
+    torch.cuda.synchronize()
+
+    wall, kernel_ms = time_steps(batch, step_fn, args.steps, args.warmup, dist)
+    total_steps = n * world * args.steps
+    value = total_steps / wall
+
+    b_alg = B_ALG[args.env] - (4 if args.policy == "random" else 0)
+    achieved = b_alg * n / (kernel_ms * 1e-3) / 1e9
+    out = {
+        "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": "%s VectorEnv.Step, %d envs/GPU, single-step kernel, auto-reset + RecordEpisodeStatistics fused, "
+                        "%s, %s mode" % (args.env, n, "device-resident random actions (zero-copy path)"
+                                         if args.policy == "device" else "actions sampled in-kernel", args.mode),
+            "envs_per_gpu": n, "sharding": "independent env shards, no data-path collective",
+        },
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "kernel_ms": kernel_ms, "bytes_per_env_step": b_alg},
+    }
+
+    # episode statistics: device reduction, then one RCCL all-reduce across ranks
+    s = batch.stats()
+    st = torch.tensor([float(s.episodes), float(s.sum_length), s.sum_return], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(st, op=dist.ReduceOp.SUM)
+    ep = st.tolist()
+    out["episode_stats"] = {"episodes": int(ep[0]), "mean_length": ep[1] / max(ep[0], 1), "mean_return": ep[2] / max(ep[0], 1)}
+
+    if rank == 0 and world == 1 and not args.no_extra and args.env == "cartpole":
+        out["extra"] = extra_measurements(ctx, n, stream_ptr)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.env)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def extra_measurements(ctx, n, stream_ptr):
+    """Secondary numbers named by the headline metric: Acrobot single-step (reference dynamics)
+    and the fused 64-step RK4/binary64 rollout (FP64 vector-ALU bound)."""
+    res = {}
+    flags = L.AUTORESET | L.RECORD_STATS
+    b = DeviceBatch(ctx, L.ENV_ACROBOT, n, seed=1, flags=flags)
+    b.reset()
+    _, ms = time_steps(b, lambda: b.step_random(stream_ptr), 20, 3, None)
+    res["acrobot_euler_exact_single_step"] = {"env_steps_per_s": n / (ms * 1e-3), "kernel_ms": ms,
+                                             "hbm_GBps": (B_ALG["acrobot"] - 4) * n / (ms * 1e-3) / 1e9}
+    b.close()
+    k = 64
+    b = DeviceBatch(ctx, L.ENV_ACROBOT, n, seed=1, flags=flags | L.ACROBOT_RK4)
+    b.reset()
+    _, ms = time_steps(b, lambda: b.rollout(k, L.POLICY_RANDOM, None, stream_ptr), 3, 1, None)
+    rate = n * k / (ms * 1e-3)
+    res["acrobot_rk4_fp64_rollout64"] = {"env_steps_per_s": rate, "kernel_ms": ms,
+                                         "fp64_TFLOPs_arith_only": rate * ACROBOT_RK4_FLOPS / 1e12,
+                                         "frac_of_fp64_valu_peak_arith_only": rate * ACROBOT_RK4_FLOPS / 1e12 / FP64_VALU_PEAK_TFLOPS}
+    b.close()
+    return res
+
+
+if __name__ == "__main__":
+    main()

@@ -282,7 +282,10 @@ def test_fast32_mode_within_tolerance(oracle):
             a = random_actions(rng, env_id, n)
             g.step_host(a); o.step(a)
             gr, gi = g.get_state(); orr, oi = o.get_state()
-            err = np.abs(gr.astype(np.float64) - orr) / np.maximum(np.abs(orr), 1e-3)
+            # relative to the value, floored at 0.1: a velocity that cancels to ~0, or cos(theta)
+            # next to its zero crossing, has no meaningful relative error in binary32 (half an
+            # ulp of theta ~ 1.57 is already 6e-8 absolute)
+            err = np.abs(gr.astype(np.float64) - orr) / np.maximum(np.abs(orr), 1e-1)
             assert err.max() <= 1e-5, (env_id, t, err.max())
             g.set_state(orr, oi)  # teacher forcing per step
 
