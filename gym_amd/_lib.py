@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgymx.so")
+# GYMX_LIB selects another build of the same library (A/B runs of kernel variants)
+LIB_PATH = os.environ.get("GYMX_LIB") or os.path.join(_HERE, "lib", "libgymx.so")
 
 GX_OK, GX_ERR_INVALID, GX_ERR_HIP, GX_ERR_OOM, GX_ERR_UNSUPPORTED, GX_ERR_RCCL = range(6)
 

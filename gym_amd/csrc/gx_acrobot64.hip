@@ -11,7 +11,9 @@
 //
 // Every a*b+c is an explicit fma() (and nothing else is contracted) so that a
 // CPU restatement written with the same fma() calls can match wherever the
-// sin/cos results agree.
+// sin/cos results agree; sin and cos come from the reduction-light binary64
+// routine of gx_math.h (last-place accurate, so results differ from a libm
+// build by parts in 10^16).
 #pragma clang fp contract(off)
 
 #include "gx_classic_kernel.h"
@@ -30,24 +32,27 @@ struct Acrobot64 {
   static constexpr int NACT = 3;
   static constexpr bool kCheckAction = true;
   static __device__ __forceinline__ bool action_valid(Act a) { return (uint32_t)a <= 2u; }
+  // the angles are wrapped to [-pi, pi] and the velocities bounded after every step, so
+  // every sin/cos argument of an RK4 stage stays below 16 for any finite state
+  static constexpr bool kAlwaysBounded = true;
 
   static __device__ __forceinline__ void reset(double (&s)[NS], const RngKey& key, uint64_t env) {
-    Draws d0 = philox_block(key, env, 0, 0), d1 = philox_block(key, env, 0, 1);
-    s[0] = fma(d0.uniform(0), 0.2, -0.1);
-    s[1] = fma(d0.uniform(1), 0.2, -0.1);
-    s[2] = fma(d1.uniform(0), 0.2, -0.1);
-    s[3] = fma(d1.uniform(1), 0.2, -0.1);
+    Draws d = philox_block(key, env, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; i++) s[i] = fma(d.uniform(i), 0.2, -0.1);
   }
 
   static __device__ __forceinline__ void dsdt(const double (&y)[4], double u, double (&dy)[4]) {
     const double g = 9.8;
     const double t1 = y[0], t2 = y[1], w1 = y[2], w2 = y[3];
-    double s2, c2;
-    ::sincos(t2, &s2, &c2);
+    double s2, c2, unused, c12, c1;
+    math::sincos_bounded(t2, s2, c2);
+    math::sincos_bounded(t1 + t2 - M_PI / 2.0, unused, c12);
+    math::sincos_bounded(t1 - M_PI / 2.0, unused, c1);
     const double d1 = c2 + 3.5;
     const double d2 = fma(0.5, c2, 1.25);
-    const double phi2 = (0.5 * g) * ::cos(t1 + t2 - M_PI / 2.0);
-    double phi1 = fma(1.5 * g, ::cos(t1 - M_PI / 2.0), phi2);
+    const double phi2 = (0.5 * g) * c12;
+    double phi1 = fma(1.5 * g, c1, phi2);
     phi1 = fma(-(w2 * s2), w1, phi1);
     phi1 = fma(-0.5 * (w2 * s2), w2, phi1);
     const double r = d2 / d1;
@@ -66,7 +71,7 @@ struct Acrobot64 {
     return x;
   }
 
-  template <int MODE>
+  template <int MODE, bool BOUNDED>
   static __device__ __forceinline__ void step(double (&s)[NS], int32_t& steps, Act action, Rew& reward, bool& done) {
     const double dt = 0.2;
     const double u = action == 0 ? -1.0 : (action == 2 ? 1.0 : 0.0);
@@ -95,16 +100,19 @@ struct Acrobot64 {
 #pragma unroll
     for (int i = 0; i < 4; i++) s[i] = y[i];
     steps++;
-    done = (-::cos(y[0]) - ::cos(y[1] + y[0]) > 1.0) || steps >= 500;
+    double sa, ca, sb, cb;
+    math::sincos_bounded(y[0], sa, ca);
+    math::sincos_bounded(y[1] + y[0], sb, cb);
+    done = (-ca - cb > 1.0) || steps >= 500;
     reward = done ? 0.0f : -1.0f;
   }
 
   // the reference's observation layout (Envs.Acrobot.cs:77-82)
   static __device__ __forceinline__ void observe(const double (&s)[NS], float (&o)[NOBS]) {
     double sn, cs;
-    ::sincos(s[0], &sn, &cs);
+    math::sincos_bounded(s[0], sn, cs);
     o[0] = (float)cs; o[1] = (float)sn;
-    ::sincos(s[1], &sn, &cs);
+    math::sincos_bounded(s[1], sn, cs);
     o[2] = (float)cs; o[3] = (float)sn;
     o[4] = (float)s[2];
     o[5] = (float)s[3];
@@ -113,8 +121,8 @@ struct Acrobot64 {
   static __device__ __forceinline__ Act sample(const Draws& d) { return d.below(0, NACT); }
 };
 
-hipError_t launch_acrobot64_step(const StepArgs& a, int policy, dim3 grid, hipStream_t stream) {
-  return launch_step_env<Acrobot64>(a, GX_MODE_EXACT, policy, grid, stream);
+hipError_t launch_acrobot64_step(const StepArgs& a, int policy, bool fused, dim3 grid, hipStream_t stream) {
+  return launch_step_env<Acrobot64>(a, GX_MODE_EXACT, policy, fused, true, grid, stream);
 }
 hipError_t launch_acrobot64_reset(const StepArgs& a, int only_observe, dim3 grid, hipStream_t stream) {
   return launch_reset_env<Acrobot64>(a, only_observe, grid, stream);

@@ -79,6 +79,10 @@ struct gx_vec {
   uint32_t* h_error = nullptr;  // pinned
   StatSlot* h_stat = nullptr;   // pinned
   bool frames_valid = false;
+  // set by set_state: the state may violate the invariants the BOUNDED kernels rely on
+  // until one step with auto-reset has run
+  bool state_dirty = false;
+  uint32_t sweep_parity = 0;  // flips every step launch: alternate launches sweep in opposite directions
   // tabular
   int table_states = 0, table_actions = 0, table_outcomes = 1, start_state = 0, step_limit = 0;
   size_t table_lds_bytes = 0;
@@ -373,6 +377,7 @@ StepArgs make_args(const gx_vec* v, const void* d_actions, int k_steps, uint64_t
   a.flags = v->desc.flags;
   a.time_limit = v->desc.time_limit;
   a.k_steps = k_steps;
+  a.reverse = v->sweep_parity;
   a.table_states = v->table_states;
   a.table_actions = v->table_actions;
   a.table_outcomes = v->table_outcomes;
@@ -384,8 +389,11 @@ StepArgs make_args(const gx_vec* v, const void* d_actions, int k_steps, uint64_t
 int launch_step(gx_vec* v, const void* d_actions, int k_steps, uint64_t action_stride, int policy, hipStream_t stream) {
   StepArgs a = make_args(v, d_actions, k_steps, action_stride);
   hipError_t e;
-  if (v->is_acrobot64) e = launch_acrobot64_step(a, policy, v->grid, stream);
-  else if (v->is_classic) e = launch_classic_step(v->desc.env_id, a, v->desc.mode, policy, v->grid, stream);
+  const uint32_t both = GX_AUTORESET | GX_RECORD_STATS;
+  const bool fused = (v->desc.flags & both) == both && v->desc.time_limit == 0;
+  const bool bounded = (v->desc.flags & GX_AUTORESET) && !v->state_dirty;
+  if (v->is_acrobot64) e = launch_acrobot64_step(a, policy, fused, v->grid, stream);
+  else if (v->is_classic) e = launch_classic_step(v->desc.env_id, a, v->desc.mode, policy, fused, bounded, v->grid, stream);
   else if (v->is_tabular) e = launch_tabular_step(v->desc.env_id, a, policy, v->grid, v->table_lds_bytes, stream);
   else {
     e = launch_pong_step(a, policy, v->grid, stream);
@@ -394,6 +402,8 @@ int launch_step(gx_vec* v, const void* d_actions, int k_steps, uint64_t action_s
   }
   if (e != hipSuccess) return fail(GX_ERR_HIP, "step kernel launch failed: %s", hipGetErrorString(e));
   v->tick += (uint64_t)k_steps;
+  v->state_dirty = false;
+  v->sweep_parity ^= 1u;
   return GX_OK;
 }
 
@@ -625,6 +635,7 @@ extern "C" int gx_vec_set_state(gx_vec* v, const void* host, size_t bytes) {
   rc = copy_rows(v->d_int, h + (size_t)v->info.n_real * v->n * rsz, 4, v->info.n_int, v->n, v->stride, v->n, hipMemcpyHostToDevice, c->copy);
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(c->copy));
+  v->state_dirty = true;
   StepArgs a = make_args(v, nullptr, 1, 0);
   if (v->is_pong) HIP_TRY(launch_pong_raster(a, v->d_frames, c->compute));
   if (v->is_acrobot64) HIP_TRY(launch_acrobot64_reset(a, 1, v->grid, c->compute));

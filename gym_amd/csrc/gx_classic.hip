@@ -13,7 +13,15 @@
 
 namespace gx {
 
-// ------------------------------------------------------------------ envs ---
+// `x / total_mass` with total_mass = 1.0f + 0.1f: a correctly rounded quotient from three
+// multiply-adds (bit-identical to the divide for every float of moderate size), with the
+// true divide kept for zero, infinities, NaN and the far ends of the exponent range.
+__device__ __forceinline__ float div_total_mass(float x) {
+  float q = math::div_by_total_mass(x);
+  if (__builtin_expect(!math::div_fast_range(x), 0)) q = x / (1.0f + 0.1f);
+  return q;
+}
+
 // Each env: NS real components, action type, reward type, Reset and Step that
 // follow the cited reference lines.  `steps` is the env's own `_steps` field.
 
@@ -26,26 +34,25 @@ struct CartPole {
   using Act = int32_t;
   using Rew = float;
   using EpRet = int32_t;
+  static constexpr int NACT = 2;
   static constexpr bool kCheckAction = false;
   static __device__ __forceinline__ bool action_valid(Act) { return true; }
-  static constexpr int NACT = 2;
+  // theta is unbounded when the pole keeps falling without a reset; with auto-reset every
+  // stored theta is within the 12-degree threshold (Envs.CartPole.cs:45,70) or a fresh draw
+  static constexpr bool kAlwaysBounded = false;
 
   // Envs.CartPole.cs:22-32
   static __device__ __forceinline__ void reset(float (&s)[NS], const RngKey& key, uint64_t env) {
-    Draws d0 = philox_block(key, env, 0, 0), d1 = philox_block(key, env, 0, 1);
-    s[0] = (float)(d0.uniform(0) * 0.1 - 0.05);
-    s[1] = (float)(d0.uniform(1) * 0.1 - 0.05);
-    s[2] = (float)(d1.uniform(0) * 0.1 - 0.05);
-    s[3] = (float)(d1.uniform(1) * 0.1 - 0.05);
+    Draws d = philox_block(key, env, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; i++) s[i] = (float)(d.uniform(i) * 0.1 - 0.05);
   }
 
   // Envs.CartPole.cs:34-75
-  template <int MODE>
+  template <int MODE, bool BOUNDED>
   static __device__ __forceinline__ void step(float (&s)[NS], int32_t& steps, Act action, Rew& reward, bool& done) {
     const float gravity = 9.8f;
-    const float masscart = 1.0f;
     const float masspole = 0.1f;
-    const float total_mass = masscart + masspole;
     const float length = 0.5f;
     const float polemass_length = masspole * length;
     const float force_mag = 10.0f;
@@ -53,15 +60,20 @@ struct CartPole {
     const float theta_threshold_radians = 12 * (float)M_PI / 180;
     const float x_threshold = 2.4f;
 
+#if GX_DEBUG_COPY_ONLY
+    // bandwidth experiment: same rows moved, no dynamics
+    s[0] += 1.0f; s[1] += (float)action; steps++; done = s[2] > 1e30f; reward = s[3];
+    return;
+#endif
     float x = s[0], xDot = s[1], theta = s[2], thetaDot = s[3];
     float force = action == 1 ? force_mag : -force_mag;
     float sintheta, costheta;
-    Trig<MODE>::sincos(theta, sintheta, costheta);
+    Trig<MODE, BOUNDED>::sincos_quarter(theta, sintheta, costheta);
 
-    float temp = (force + polemass_length * thetaDot * thetaDot * sintheta) / total_mass;
+    float temp = div_total_mass(force + polemass_length * thetaDot * thetaDot * sintheta);
     float thetaacc = (gravity * sintheta - costheta * temp) /
-                     (length * (4.0f / 3.0f - masspole * costheta * costheta / total_mass));
-    float xacc = temp - polemass_length * thetaacc * costheta / total_mass;
+                     (length * (4.0f / 3.0f - div_total_mass(masspole * costheta * costheta)));
+    float xacc = temp - div_total_mass(polemass_length * thetaacc * costheta);
 
     x += tau * xDot;
     xDot += tau * xacc;
@@ -86,9 +98,12 @@ struct MountainCar {
   using Act = int32_t;
   using Rew = float;
   using EpRet = int32_t;
+  static constexpr int NACT = 3;
   static constexpr bool kCheckAction = false;
   static __device__ __forceinline__ bool action_valid(Act) { return true; }
-  static constexpr int NACT = 3;
+  // the position has no upper clamp (Envs.MountainCar.cs:38-44): past the goal it only stops
+  // growing when the env is reset
+  static constexpr bool kAlwaysBounded = false;
 
   // Envs.MountainCar.cs:22-30
   static __device__ __forceinline__ void reset(float (&s)[NS], const RngKey& key, uint64_t env) {
@@ -98,11 +113,11 @@ struct MountainCar {
   }
 
   // Envs.MountainCar.cs:32-50
-  template <int MODE>
+  template <int MODE, bool BOUNDED>
   static __device__ __forceinline__ void step(float (&s)[NS], int32_t& steps, Act action, Rew& reward, bool& done) {
     float position = s[0], velocity = s[1];
     float force = (float)(action - 1);
-    velocity += 0.001f * force - 0.0025f * Trig<MODE>::cos(3 * position);
+    velocity += 0.001f * force - 0.0025f * Trig<MODE, BOUNDED>::cos(3 * position);
     velocity = clampf(velocity, -0.07f, 0.07f);
     position += velocity;
     if (position < -1.2f) {
@@ -128,6 +143,7 @@ struct MountainCarContinuous {
   using EpRet = double;
   static constexpr bool kCheckAction = false;
   static __device__ __forceinline__ bool action_valid(Act) { return true; }
+  static constexpr bool kAlwaysBounded = false;
 
   // Envs.MountainCarContinuous.cs:19-27
   static __device__ __forceinline__ void reset(float (&s)[NS], const RngKey& key, uint64_t env) {
@@ -135,11 +151,11 @@ struct MountainCarContinuous {
   }
 
   // Envs.MountainCarContinuous.cs:29-49
-  template <int MODE>
+  template <int MODE, bool BOUNDED>
   static __device__ __forceinline__ void step(float (&s)[NS], int32_t& steps, Act action, Rew& reward, bool& done) {
     float position = s[0], velocity = s[1];
     float force = clampf(action, -1.0f, 1.0f);
-    velocity += force * 0.0015f - 0.0025f * Trig<MODE>::cos(3 * position);
+    velocity += force * 0.0015f - 0.0025f * Trig<MODE, BOUNDED>::cos(3 * position);
     velocity = clampf(velocity, -0.07f, 0.07f);
     position += velocity;
     if (position < -1.2f) {
@@ -168,18 +184,21 @@ struct Pendulum {
   using EpRet = double;
   static constexpr bool kCheckAction = false;
   static __device__ __forceinline__ bool action_valid(Act) { return true; }
+  // theta comes out of atan2 every step and the speed is clamped to 8 before it is
+  // integrated (Envs.Pendulum.cs:40,46-47): every angle is below 4 for any finite state
+  static constexpr bool kAlwaysBounded = true;
 
   // Envs.Pendulum.cs:19-28
   static __device__ __forceinline__ void reset(float (&s)[NS], const RngKey& key, uint64_t env) {
     Draws d0 = philox_block(key, env, 0, 0);
     float theta = (float)(d0.uniform(0) * 2 * M_PI - M_PI);
     float thetaDot = (float)(d0.uniform(1) * 1 - 0.5);
-    Trig<GX_MODE_EXACT>::sincos(theta, s[1], s[0]);
+    Trig<GX_MODE_EXACT, true>::sincos(theta, s[1], s[0]);
     s[2] = thetaDot;
   }
 
   // Envs.Pendulum.cs:30-60
-  template <int MODE>
+  template <int MODE, bool BOUNDED>
   static __device__ __forceinline__ void step(float (&s)[NS], int32_t& steps, Act action, Rew& reward, bool& done) {
     const float max_speed = 8.0f;
     const float max_torque = 2.0f;
@@ -188,15 +207,16 @@ struct Pendulum {
     const float m = 1.0f;
     const float l = 1.0f;
 
-    float theta = Trig<MODE>::atan2(s[1], s[0]);
+    float theta = Trig<MODE, BOUNDED>::atan2(s[1], s[0]);
     float thetaDot = s[2];
     float u = clampf(action, -max_torque, max_torque);
 
-    float new_thetaDot = thetaDot + (-3 * g / (2 * l) * Trig<MODE>::sin_plus_pi(theta) + 3.0f / (m * l * l) * u) * dt;
+    float new_thetaDot =
+        thetaDot + (-3 * g / (2 * l) * Trig<MODE, BOUNDED>::sin_plus_pi(theta) + 3.0f / (m * l * l) * u) * dt;
     new_thetaDot = clampf(new_thetaDot, -max_speed, max_speed);
     float new_theta = theta + new_thetaDot * dt;
 
-    Trig<MODE>::sincos(new_theta, s[1], s[0]);
+    Trig<MODE, BOUNDED>::sincos(new_theta, s[1], s[0]);
     s[2] = new_thetaDot;
     steps++;
 
@@ -218,22 +238,27 @@ struct Acrobot {
   using Rew = float;
   using EpRet = int32_t;
   static constexpr int NACT = 3;
+  static constexpr bool kCheckAction = true;
+  static __device__ __forceinline__ bool action_valid(Act a) { return (uint32_t)a <= 2u; }
+  // both angles come out of atan2 every step and the velocities are clamped to 4pi / 9pi
+  // before they are integrated (Envs.Acrobot.cs:47-48,71-74): every angle is below 15
+  static constexpr bool kAlwaysBounded = true;
 
   // Envs.Acrobot.cs:22-28
   static __device__ __forceinline__ void reset(float (&s)[NS], const RngKey& key, uint64_t env) {
+    Draws d0 = philox_block(key, env, 0, 0), d1 = philox_block(key, env, 0, 1);
 #pragma unroll
-    for (int b = 0; b < 3; b++) {
-      Draws d = philox_block(key, env, 0, b);
-      s[2 * b] = (float)(d.uniform(0) * 0.1 - 0.05);
-      s[2 * b + 1] = (float)(d.uniform(1) * 0.1 - 0.05);
-    }
+    for (int i = 0; i < 4; i++) s[i] = (float)(d0.uniform(i) * 0.1 - 0.05);
+    s[4] = (float)(d1.uniform(0) * 0.1 - 0.05);
+    s[5] = (float)(d1.uniform(1) * 0.1 - 0.05);
   }
 
   // Envs.Acrobot.cs:30-91.  An action outside {0,1,2} throws in the reference
   // (Envs.Acrobot.cs:51); the host validates before launch where it can and
-  // the kernel treats such a lane as torque 0.
-  template <int MODE>
+  // the kernel treats such a lane as torque 0 and raises the error flag.
+  template <int MODE, bool BOUNDED>
   static __device__ __forceinline__ void step(float (&s)[NS], int32_t& steps, Act action, Rew& reward, bool& done) {
+    using T = Trig<MODE, BOUNDED>;
     const float LINK_LENGTH_1 = 1.0f;
     const float LINK_LENGTH_2 = 1.0f;
     const float LINK_MASS_1 = 1.0f;
@@ -247,24 +272,24 @@ struct Acrobot {
     const float dt = 0.2f;
     const float g = 9.8f;
 
-    float theta1 = Trig<MODE>::atan2(s[1], s[0]);
-    float theta2 = Trig<MODE>::atan2(s[3], s[2]);
+    float theta1 = T::atan2(s[1], s[0]);
+    float theta2 = T::atan2(s[3], s[2]);
     float dtheta1 = s[4];
     float dtheta2 = s[5];
     float u = action == 0 ? -1.0f : (action == 2 ? 1.0f : 0.0f);
 
     float sin2, cos2;
-    Trig<MODE>::sincos(theta2, sin2, cos2);
+    T::sincos(theta2, sin2, cos2);
 
     float d1 = LINK_MASS_1 * LINK_COM_POS_1 * LINK_COM_POS_1 +
                LINK_MASS_2 * (LINK_LENGTH_1 * LINK_LENGTH_1 + LINK_COM_POS_2 * LINK_COM_POS_2 +
                               2 * LINK_LENGTH_1 * LINK_COM_POS_2 * cos2) +
                LINK_MOI_1 + LINK_MOI_2;
     float d2 = LINK_MASS_2 * (LINK_COM_POS_2 * LINK_COM_POS_2 + LINK_LENGTH_1 * LINK_COM_POS_2 * cos2) + LINK_MOI_2;
-    float phi2 = LINK_MASS_2 * LINK_COM_POS_2 * g * Trig<MODE>::cos_minus_half_pi(theta1 + theta2);
+    float phi2 = LINK_MASS_2 * LINK_COM_POS_2 * g * T::cos_minus_half_pi(theta1 + theta2);
     float phi1 = -LINK_MASS_2 * LINK_LENGTH_1 * LINK_COM_POS_2 * dtheta2 * dtheta2 * sin2 -
                  2 * LINK_MASS_2 * LINK_LENGTH_1 * LINK_COM_POS_2 * dtheta2 * dtheta1 * sin2 +
-                 (LINK_MASS_1 * LINK_COM_POS_1 + LINK_MASS_2 * LINK_LENGTH_1) * g * Trig<MODE>::cos_minus_half_pi(theta1) +
+                 (LINK_MASS_1 * LINK_COM_POS_1 + LINK_MASS_2 * LINK_LENGTH_1) * g * T::cos_minus_half_pi(theta1) +
                  phi2;
     float ddtheta2 = (u + d2 / d1 * phi1 - LINK_MASS_2 * LINK_LENGTH_1 * LINK_COM_POS_2 * dtheta1 * dtheta1 * sin2 - phi2) /
                      (LINK_MASS_2 * LINK_COM_POS_2 * LINK_COM_POS_2 + LINK_MOI_2 - d2 * d2 / d1);
@@ -278,27 +303,26 @@ struct Acrobot {
     theta2 += dt * dtheta2;
 
     float c1n, s1n, c2n, s2n;
-    Trig<MODE>::sincos(theta1, s1n, c1n);
-    Trig<MODE>::sincos(theta2, s2n, c2n);
+    T::sincos(theta1, s1n, c1n);
+    T::sincos(theta2, s2n, c2n);
     s[0] = c1n; s[1] = s1n; s[2] = c2n; s[3] = s2n; s[4] = dtheta1; s[5] = dtheta2;
     steps++;
 
-    float tip_y = -LINK_LENGTH_1 * c1n - LINK_LENGTH_2 * Trig<MODE>::cos(theta1 + theta2);
+    float tip_y = -LINK_LENGTH_1 * c1n - LINK_LENGTH_2 * T::cos(theta1 + theta2);
     done = tip_y > 1.0f || steps >= 500;
     reward = done ? 0.0f : -1.0f;
   }
   static __device__ __forceinline__ Act sample(const Draws& d) { return d.below(0, NACT); }
-  static constexpr bool kCheckAction = true;
-  static __device__ __forceinline__ bool action_valid(Act a) { return (uint32_t)a <= 2u; }
 };
 
-hipError_t launch_classic_step(int env_id, const StepArgs& a, int mode, int policy, dim3 grid, hipStream_t stream) {
+hipError_t launch_classic_step(int env_id, const StepArgs& a, int mode, int policy, bool fused, bool bounded, dim3 grid,
+                               hipStream_t stream) {
   switch (env_id) {
-    case GX_ENV_CARTPOLE: return launch_step_env<CartPole>(a, mode, policy, grid, stream);
-    case GX_ENV_MOUNTAINCAR: return launch_step_env<MountainCar>(a, mode, policy, grid, stream);
-    case GX_ENV_MOUNTAINCAR_CONT: return launch_step_env<MountainCarContinuous>(a, mode, policy, grid, stream);
-    case GX_ENV_PENDULUM: return launch_step_env<Pendulum>(a, mode, policy, grid, stream);
-    case GX_ENV_ACROBOT: return launch_step_env<Acrobot>(a, mode, policy, grid, stream);
+    case GX_ENV_CARTPOLE: return launch_step_env<CartPole>(a, mode, policy, fused, bounded, grid, stream);
+    case GX_ENV_MOUNTAINCAR: return launch_step_env<MountainCar>(a, mode, policy, fused, bounded, grid, stream);
+    case GX_ENV_MOUNTAINCAR_CONT: return launch_step_env<MountainCarContinuous>(a, mode, policy, fused, bounded, grid, stream);
+    case GX_ENV_PENDULUM: return launch_step_env<Pendulum>(a, mode, policy, fused, bounded, grid, stream);
+    case GX_ENV_ACROBOT: return launch_step_env<Acrobot>(a, mode, policy, fused, bounded, grid, stream);
     default: return hipErrorInvalidValue;
   }
 }

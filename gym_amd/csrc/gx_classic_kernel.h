@@ -2,57 +2,26 @@
 //
 // An env type E supplies: Real (float or double), NS (real components), W
 // (envs per lane: 16 bytes of each SoA row per lane), Act, Rew, EpRet,
-// reset(), step<MODE>(), sample() and, when the observation is not the state
-// itself, observe().  One env per lane slot, grid-stride over the batch,
-// single step and register-resident K-step rollout in one kernel, with
+// reset(), step<MODE, BOUNDED>(), sample() and, when the observation is not
+// the state itself, observe().  One env per lane slot, grid-stride over the
+// batch, single step and register-resident K-step rollout in one kernel, with
 // auto-reset, TimeLimit and RecordEpisodeStatistics fused in.
+//
+// Two compile-time switches pick the kernel variant:
+//   FUSED   : auto-reset and RecordEpisodeStatistics on, no TimeLimit -- the
+//             throughput configuration; the wrapper flags become constants and
+//             the rows that configuration never touches disappear.
+//   BOUNDED : angles are inside the ranges the env's invariants guarantee (see
+//             gx_trig.h); the host clears it for the one step that follows a
+//             set_state and whenever auto-reset is off for an env whose angle
+//             can then grow without bound.
 #pragma once
 
 #include "gx_device.h"
 #include "gx_launch.h"
+#include "gx_trig.h"
 
 namespace gx {
-
-#ifndef M_PI
-#define M_PI 3.14159265358979323846
-#endif
-
-// ------------------------------------------------------------------ math ---
-template <int MODE>
-struct Trig;
-
-// EXACT: Math.Sin/Cos/Atan2 take and return double; the C# source casts the
-// result to float, which rounds once.
-template <>
-struct Trig<GX_MODE_EXACT> {
-  static __device__ __forceinline__ void sincos(float x, float& s, float& c) {
-    double sd, cd;
-    ::sincos((double)x, &sd, &cd);
-    s = (float)sd;
-    c = (float)cd;
-  }
-  static __device__ __forceinline__ float cos(float x) { return (float)::cos((double)x); }
-  static __device__ __forceinline__ float sin(float x) { return (float)::sin((double)x); }
-  // (float)Math.Cos(x - Math.PI / 2.0) with x a float: the subtraction is in double
-  static __device__ __forceinline__ float cos_minus_half_pi(float x) { return (float)::cos((double)x - M_PI / 2.0); }
-  // (float)Math.Sin(x + Math.PI)
-  static __device__ __forceinline__ float sin_plus_pi(float x) { return (float)::sin((double)x + M_PI); }
-  static __device__ __forceinline__ float atan2(float y, float x) { return (float)::atan2((double)y, (double)x); }
-};
-
-// FAST32: binary32 device trig, identities applied.
-template <>
-struct Trig<GX_MODE_FAST32> {
-  static __device__ __forceinline__ void sincos(float x, float& s, float& c) { ::sincosf(x, &s, &c); }
-  static __device__ __forceinline__ float cos(float x) { return ::cosf(x); }
-  static __device__ __forceinline__ float sin(float x) { return ::sinf(x); }
-  static __device__ __forceinline__ float cos_minus_half_pi(float x) { return ::sinf(x); }
-  static __device__ __forceinline__ float sin_plus_pi(float x) { return -::sinf(x); }
-  static __device__ __forceinline__ float atan2(float y, float x) { return ::atan2f(y, x); }
-};
-
-// Math.Clamp(float, float, float)
-__device__ __forceinline__ float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // ------------------------------------------------------- vector row access ---
 template <class T, int W>
@@ -89,9 +58,84 @@ __device__ __forceinline__ void store_flags(uint8_t* base, uint64_t group, const
   }
 }
 
+// Non-temporal forms for rows the kernels only write.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+template <class T, int W>
+__device__ __forceinline__ void store_row_nt(T* base, uint64_t group, const T (&in)[W]) {
+  constexpr int kDwords = (int)(sizeof(T) * W / 4);
+  uint32_t d[kDwords];
+  __builtin_memcpy(d, in, sizeof(T) * W);
+  uint32_t* dst = reinterpret_cast<uint32_t*>(base) + group * kDwords;
+  if constexpr (kDwords == 2) {
+    u32x2 v = {d[0], d[1]};
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x2*>(dst));
+  } else {
+#pragma unroll
+    for (int i = 0; i < kDwords; i += 4) {
+      u32x4 v = {d[i], d[i + 1], d[i + 2], d[i + 3]};
+      __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst + i));
+    }
+  }
+}
+template <int W>
+__device__ __forceinline__ void store_flags_nt(uint8_t* base, uint64_t group, const bool (&b)[W]) {
+  if constexpr (W == 4) {
+    const uint32_t v = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
+    __builtin_nontemporal_store(v, reinterpret_cast<uint32_t*>(base) + group);
+  } else {
+    const uint16_t v = (uint16_t)((uint32_t)b[0] | ((uint32_t)b[1] << 8));
+    __builtin_nontemporal_store(v, reinterpret_cast<uint16_t*>(base) + group);
+  }
+}
+
+// ------------------------------------------------- per-thread statistics ---
+// Integer-valued returns (every env but MountainCarContinuous and Pendulum)
+// accumulate in integer registers, branch-free.
+template <class EpRet>
+struct ThreadStats;
+
+template <>
+struct ThreadStats<int32_t> {
+  int32_t episodes = 0, sum_length = 0;
+  long long sum_return = 0, sum_return_sq = 0;
+  int32_t min_return = 0x7FFFFFFF, max_return = (int32_t)0x80000000;
+  __device__ __forceinline__ void add(bool d, int32_t ret, int32_t len) {
+    episodes += d ? 1 : 0;
+    sum_length += d ? len : 0;
+    const int32_t r = d ? ret : 0;
+    sum_return += r;
+    sum_return_sq += (long long)r * r;
+    min_return = d && ret < min_return ? ret : min_return;
+    max_return = d && ret > max_return ? ret : max_return;
+  }
+  __device__ __forceinline__ StatAcc widen() const {
+    StatAcc a;
+    a.episodes = episodes; a.sum_return = (double)sum_return; a.sum_length = sum_length;
+    a.sum_return_sq = (double)sum_return_sq;
+    if (episodes) { a.min_return = (double)min_return; a.max_return = (double)max_return; }
+    return a;
+  }
+};
+
+template <>
+struct ThreadStats<double> {
+  StatAcc acc;
+  __device__ __forceinline__ void add(bool d, double ret, int32_t len) {
+    if (d) acc.add(ret, len);
+  }
+  __device__ __forceinline__ StatAcc widen() const { return acc; }
+};
+
 // ---------------------------------------------------------------- kernels ---
-template <class E, int MODE, int POLICY>
-__global__ void __launch_bounds__(kBlock) classic_step_kernel(StepArgs a) {
+// minimum resident waves per SIMD the fused kernels are compiled for (caps their registers)
+#ifndef GX_FUSED_MIN_WAVES
+#define GX_FUSED_MIN_WAVES 1
+#endif
+
+template <class E, int MODE, int POLICY, bool FUSED, bool BOUNDED>
+__global__ void __launch_bounds__(kBlock, (FUSED && BOUNDED) ? GX_FUSED_MIN_WAVES : 1) classic_step_kernel(StepArgs a) {
   using Real = typename E::Real;
   using Act = typename E::Act;
   using Rew = typename E::Rew;
@@ -99,15 +143,20 @@ __global__ void __launch_bounds__(kBlock) classic_step_kernel(StepArgs a) {
   constexpr int NS = E::NS;
   constexpr int W = E::W;
 
-  const bool autoreset = (a.flags & GX_AUTORESET) != 0;
-  const bool record = (a.flags & GX_RECORD_STATS) != 0;
-  const int32_t time_limit = a.time_limit;
+  const bool autoreset = FUSED ? true : (a.flags & GX_AUTORESET) != 0;
+  const bool record = FUSED ? true : (a.flags & GX_RECORD_STATS) != 0;
+  const int32_t time_limit = FUSED ? 0 : a.time_limit;
+  int32_t* const ep_length_row = FUSED ? nullptr : a.ep_length;
+  uint8_t* const truncated_row = FUSED ? nullptr : a.truncated;
   Real* const sreal = static_cast<Real*>(a.state_real);
   int32_t* const steps_row = a.state_int;  // these envs have one int row: the step counter
-  StatAcc acc;
+  ThreadStats<EpRet> acc;
 
   const uint64_t ngroups = (a.num_envs + (W - 1)) / W;
-  for (uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q < ngroups; q += (uint64_t)gridDim.x * kBlock) {
+  for (uint64_t it = (uint64_t)blockIdx.x * kBlock + threadIdx.x; it < ngroups; it += (uint64_t)gridDim.x * kBlock) {
+    // consecutive launches sweep the batch in opposite directions: the rows a sweep touched
+    // last are still in the 256 MiB memory-side cache when the next sweep starts there
+    const uint64_t q = a.reverse ? ngroups - 1 - it : it;
     Real s[W][NS];
     int32_t steps[W];
     EpRet ep_ret[W] = {};
@@ -122,7 +171,7 @@ __global__ void __launch_bounds__(kBlock) classic_step_kernel(StepArgs a) {
     load_row<int32_t, W>(steps_row, q, steps);
     if (record) {
       load_row<EpRet, W>(static_cast<const EpRet*>(a.ep_return), q, ep_ret);
-      if (a.ep_length) load_row<int32_t, W>(a.ep_length, q, ep_len);
+      if (ep_length_row) load_row<int32_t, W>(ep_length_row, q, ep_len);
     }
 
     Rew reward[W];
@@ -132,15 +181,16 @@ __global__ void __launch_bounds__(kBlock) classic_step_kernel(StepArgs a) {
       Act act[W];
       if (POLICY == GX_POLICY_DEVICE_ACTIONS)
         load_row<Act, W>(static_cast<const Act*>(a.actions) + (uint64_t)k * a.action_stride, q, act);
+      const uint64_t env0 = a.env_index_base + q * W;
+      uint32_t pending = 0;  // envs of this lane that finished in this step
 #pragma unroll
       for (int j = 0; j < W; j++) {
-        const uint64_t env = a.env_index_base + q * W + j;
-        if (POLICY == GX_POLICY_RANDOM) act[j] = E::sample(philox_block(key, env, 2, 0));
+        if (POLICY == GX_POLICY_RANDOM) act[j] = E::sample(philox_block(key, env0 + j, 2, 0));
         if (E::kCheckAction && POLICY == GX_POLICY_DEVICE_ACTIONS) {
           if (!E::action_valid(act[j]) && q * W + j < a.num_envs) atomicOr(a.error_flag, 1u);
         }
         bool d;
-        E::template step<MODE>(s[j], steps[j], act[j], reward[j], d);
+        E::template step<MODE, BOUNDED>(s[j], steps[j], act[j], reward[j], d);
         // Wrappers.TimeLimit.cs:26-31; its counter always equals the env's own
         bool t = time_limit > 0 && steps[j] >= time_limit;
         d = d || t;
@@ -150,16 +200,40 @@ __global__ void __launch_bounds__(kBlock) classic_step_kernel(StepArgs a) {
           // EnvWrapper.cs:46-55
           ep_ret[j] += (EpRet)reward[j];
           ep_len[j] += 1;
-          if (d) {
-            const int len = a.ep_length ? ep_len[j] : steps[j];
-            if (q * W + j < a.num_envs) acc.add((double)ep_ret[j], len);
-            ep_ret[j] = 0;
-            ep_len[j] = 0;
-          }
+          acc.add(d && q * W + j < a.num_envs, ep_ret[j], ep_length_row ? ep_len[j] : steps[j]);
+          ep_ret[j] = d ? (EpRet)0 : ep_ret[j];
+          ep_len[j] = d ? 0 : ep_len[j];
         }
-        if (autoreset && d) {
-          E::reset(s[j], key, env);
-          steps[j] = 0;
+        pending |= d ? (1u << j) : 0u;
+#if GX_SERIALIZE_ENVS
+        // Make the next env's inputs look dependent on this env's result, so the compiler
+        // evaluates the envs of a lane one after the other instead of interleaving their
+        // long double-precision chains: a quarter of the live registers, more resident
+        // waves, and the waves hide the latency the interleave was hiding.
+        if (j + 1 < W) {
+#pragma unroll
+          for (int c = 0; c < NS; c++) asm volatile("" : "+v"(s[j + 1][c]) : "v"(s[j][NS - 1]));
+        }
+#endif
+      }
+      // Auto-reset, compacted: each lane resets one finished env per round, so a
+      // wave runs the RNG max-per-lane times instead of once per env slot.
+      if (autoreset) {
+        while (__any(pending != 0)) {
+          if (pending) {
+            const int jj = __ffs((int)pending) - 1;
+            Real fresh[NS];
+            E::reset(fresh, key, env0 + (uint64_t)jj);
+#pragma unroll
+            for (int j = 0; j < W; j++) {
+              if (jj == j) {
+#pragma unroll
+                for (int c = 0; c < NS; c++) s[j][c] = fresh[c];
+                steps[j] = 0;
+              }
+            }
+            pending &= pending - 1;
+          }
         }
       }
     }
@@ -174,11 +248,12 @@ __global__ void __launch_bounds__(kBlock) classic_step_kernel(StepArgs a) {
     store_row<int32_t, W>(steps_row, q, steps);
     if (record) {
       store_row<EpRet, W>(static_cast<EpRet*>(a.ep_return), q, ep_ret);
-      if (a.ep_length) store_row<int32_t, W>(a.ep_length, q, ep_len);
+      if (ep_length_row) store_row<int32_t, W>(ep_length_row, q, ep_len);
     }
-    store_row<Rew, W>(static_cast<Rew*>(a.reward), q, reward);
-    store_flags<W>(a.done, q, done);
-    if (a.truncated) store_flags<W>(a.truncated, q, trunc);
+    // write-only rows: streamed past the caches, which stay with the rows the next step re-reads
+    store_row_nt<Rew, W>(static_cast<Rew*>(a.reward), q, reward);
+    store_flags_nt<W>(a.done, q, done);
+    if (truncated_row) store_flags_nt<W>(truncated_row, q, trunc);
     if constexpr (E::kDerivedObs) {
       float o[W][E::NOBS];
 #pragma unroll
@@ -192,7 +267,7 @@ __global__ void __launch_bounds__(kBlock) classic_step_kernel(StepArgs a) {
       }
     }
   }
-  if (record) block_commit_stats(acc, a.stat_slots);
+  if (record) block_commit_stats(acc.widen(), a.stat_slots);
 }
 
 // Reset() of every env, or (when only_observe) just the derived observation
@@ -253,18 +328,29 @@ __global__ void __launch_bounds__(kBlock) classic_sample_kernel(StepArgs a, void
 }
 
 // -------------------------------------------------------------- dispatch ---
-template <class E>
-static hipError_t launch_step_env(const StepArgs& a, int mode, int policy, dim3 grid, hipStream_t stream) {
-  if (mode == GX_MODE_EXACT) {
-    if (policy == GX_POLICY_RANDOM)
-      hipLaunchKernelGGL((classic_step_kernel<E, GX_MODE_EXACT, GX_POLICY_RANDOM>), grid, dim3(kBlock), 0, stream, a);
-    else
-      hipLaunchKernelGGL((classic_step_kernel<E, GX_MODE_EXACT, GX_POLICY_DEVICE_ACTIONS>), grid, dim3(kBlock), 0, stream, a);
+// `fused` / `bounded` are requests: an env whose angles are bounded for every
+// finite state (kAlwaysBounded) never instantiates the unbounded form.
+template <class E, int MODE, int POLICY>
+static void launch_step_variant(const StepArgs& a, bool fused, bool bounded, dim3 grid, hipStream_t stream) {
+  if (E::kAlwaysBounded) bounded = true;
+  if (fused && bounded) {
+    hipLaunchKernelGGL((classic_step_kernel<E, MODE, POLICY, true, true>), grid, dim3(kBlock), 0, stream, a);
+  } else if constexpr (E::kAlwaysBounded) {
+    hipLaunchKernelGGL((classic_step_kernel<E, MODE, POLICY, false, true>), grid, dim3(kBlock), 0, stream, a);
   } else {
-    if (policy == GX_POLICY_RANDOM)
-      hipLaunchKernelGGL((classic_step_kernel<E, GX_MODE_FAST32, GX_POLICY_RANDOM>), grid, dim3(kBlock), 0, stream, a);
-    else
-      hipLaunchKernelGGL((classic_step_kernel<E, GX_MODE_FAST32, GX_POLICY_DEVICE_ACTIONS>), grid, dim3(kBlock), 0, stream, a);
+    hipLaunchKernelGGL((classic_step_kernel<E, MODE, POLICY, false, false>), grid, dim3(kBlock), 0, stream, a);
+  }
+}
+
+template <class E>
+static hipError_t launch_step_env(const StepArgs& a, int mode, int policy, bool fused, bool bounded, dim3 grid,
+                                  hipStream_t stream) {
+  if (mode == GX_MODE_EXACT) {
+    if (policy == GX_POLICY_RANDOM) launch_step_variant<E, GX_MODE_EXACT, GX_POLICY_RANDOM>(a, fused, bounded, grid, stream);
+    else launch_step_variant<E, GX_MODE_EXACT, GX_POLICY_DEVICE_ACTIONS>(a, fused, bounded, grid, stream);
+  } else {
+    if (policy == GX_POLICY_RANDOM) launch_step_variant<E, GX_MODE_FAST32, GX_POLICY_RANDOM>(a, fused, bounded, grid, stream);
+    else launch_step_variant<E, GX_MODE_FAST32, GX_POLICY_DEVICE_ACTIONS>(a, fused, bounded, grid, stream);
   }
   return hipGetLastError();
 }

@@ -18,9 +18,9 @@ constexpr int kStatFields = 6;
 // Counter RNG.  The reference's System.Random instances are unseeded
 // (Envs.CartPole.cs:19, Spaces.Box.cs:14) and Env.Seed is empty (Env.cs:33-36),
 // so the engine defines its own stream:
-//   Philox4x32-10, key = seed, counter = (env_lo, env_hi, tick_lo,
-//   stream << 24 | tick_hi8 << 16 | block);  draw d lives in block d/2, words
-//   (1:0) when d is even and (3:2) when d is odd;  u = (x >> 11) * 2^-53.
+//   w = word (d & 3) of Philox4x32-10(key = seed, counter = (env_lo, env_hi,
+//       tick_lo, stream << 24 | tick_hi8 << 16 | d >> 2))          for draw d
+//   NextDouble() stand-in: u = w * 2^-32;   Next(n) stand-in: (w * n) >> 32
 // `tick` counts the Reset()/Step() calls made on the batch before the one that
 // consumes the draw, so no per-env RNG state is stored or moved.
 // Streams: 0 = Reset draws, 1 = draws made inside Step, 2 = random policy.
@@ -40,19 +40,12 @@ __device__ __forceinline__ RngKey make_key(uint32_t seed_lo, uint32_t seed_hi, u
   return k;
 }
 
+// One Philox block = four 32-bit draws.
 struct Draws {
   uint32_t w[4];
-  __device__ __forceinline__ uint64_t u64(int half) const {
-    return half ? (((uint64_t)w[3] << 32) | w[2]) : (((uint64_t)w[1] << 32) | w[0]);
-  }
-  // uniform double in [0,1) with 53 random bits
-  __device__ __forceinline__ double uniform(int half) const {
-    return (double)(u64(half) >> 11) * 0x1.0p-53;
-  }
-  // Random.Next(n) stand-in: high word scaled by multiply-shift
-  __device__ __forceinline__ int32_t below(int half, uint32_t n) const {
-    return (int32_t)__umulhi(half ? w[3] : w[1], n);
-  }
+  // uniform double in [0,1) with 32 random bits (exact in binary64)
+  __device__ __forceinline__ double uniform(int i) const { return (double)w[i] * 0x1.0p-32; }
+  __device__ __forceinline__ int32_t below(int i, uint32_t n) const { return (int32_t)__umulhi(w[i], n); }
 };
 
 __device__ __forceinline__ Draws philox_block(const RngKey& key, uint64_t env, uint32_t stream, uint32_t block) {
@@ -207,6 +200,7 @@ struct StepArgs {
   uint32_t flags;          // gx_flags
   int32_t time_limit;      // 0 = none
   int32_t k_steps;         // 1 for a single step
+  uint32_t reverse;        // sweep the batch back to front (alternates launch to launch)
   int32_t table_states, table_actions, table_outcomes;
   int32_t start_state;
   int32_t step_limit;

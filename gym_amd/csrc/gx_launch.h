@@ -8,12 +8,15 @@
 namespace gx {
 
 // classic control (gx_classic.hip)
-hipError_t launch_classic_step(int env_id, const StepArgs& a, int mode, int policy, dim3 grid, hipStream_t stream);
+// fused: auto-reset + RecordEpisodeStatistics on and no TimeLimit; bounded: the env's angle
+// invariants hold for the current state (see gx_classic_kernel.h)
+hipError_t launch_classic_step(int env_id, const StepArgs& a, int mode, int policy, bool fused, bool bounded, dim3 grid,
+                               hipStream_t stream);
 hipError_t launch_classic_reset(int env_id, const StepArgs& a, dim3 grid, hipStream_t stream);
 hipError_t launch_classic_sample(int env_id, const StepArgs& a, void* out, dim3 grid, hipStream_t stream);
 
 // Acrobot, RK4 in binary64 (gx_acrobot64.hip)
-hipError_t launch_acrobot64_step(const StepArgs& a, int policy, dim3 grid, hipStream_t stream);
+hipError_t launch_acrobot64_step(const StepArgs& a, int policy, bool fused, dim3 grid, hipStream_t stream);
 hipError_t launch_acrobot64_reset(const StepArgs& a, int only_observe, dim3 grid, hipStream_t stream);
 hipError_t launch_acrobot64_sample(const StepArgs& a, void* out, dim3 grid, hipStream_t stream);
 

@@ -1,0 +1,108 @@
+// Scalar math pieces shared by the kernels.  Plain C++ with explicit fma(), so
+// the same text compiles for the device (hipcc) and for the host, where
+// tests/host_math_check.cpp checks it against the platform libm.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define GX_HD __host__ __device__ __forceinline__
+#else
+#define GX_HD inline
+#endif
+
+namespace gx {
+namespace math {
+
+// sin(x) and cos(x) in binary64 for |x| <= pi/4, no argument reduction.
+// Minimax kernels of the classic fdlibm form (sin: x + x^3 S(x^2), cos:
+// 1 - x^2/2 + x^4 C(x^2)) evaluated by Horner's rule with fused multiply-adds;
+// the error stays under one unit in the last place of the double, so rounding
+// the result to float gives the same value as rounding a correctly rounded
+// double except when the true value lies within ~2^-29 (relative) of a float
+// rounding boundary.
+GX_HD void sincos_small(double x, double& s, double& c) {
+  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+               S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+               C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+  const double z = x * x;
+  double rs = fma(z, S6, S5);
+  rs = fma(z, rs, S4);
+  rs = fma(z, rs, S3);
+  rs = fma(z, rs, S2);
+  rs = fma(z, rs, S1);
+  s = fma(z * x, rs, x);
+  double rc = fma(z, C6, C5);
+  rc = fma(z, rc, C4);
+  rc = fma(z, rc, C3);
+  rc = fma(z, rc, C2);
+  rc = fma(z, rc, C1);
+  // 1 - (z/2 - z*z*rc), the subtraction of the small tail rounded once
+  const double hz = 0.5 * z;
+  c = 1.0 - fma(-(z * z), rc, hz);
+}
+
+// sin(x) and cos(x) in binary64 for |x| up to a few thousand (the angles the
+// dynamics can produce: everything derived from atan2 plus one integration
+// step stays below 16).  Cody-Waite reduction against pi/2 split in three
+// parts -- the first has 33 significant bits, so n * P1 is exact for |n| < 2^20
+// and x - n P1 is exact by cancellation -- carried as a double-double
+// (r, tail), then the same minimax kernels as sincos_small with the first
+// order tail terms, then the quadrant.  No table, no branch; inf/NaN give NaN.
+GX_HD void sincos_bounded(double x, double& s, double& c) {
+  const double INV_PIO2 = 0x1.45f306dc9c883p-1;
+  const double P1 = 0x1.921fb54400000p+0, P2 = 0x1.0b4611a626331p-34, P3 = 0x1.1701b839a2520p-88;
+  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+               S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+               C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+  const double fn = rint(x * INV_PIO2);
+  const double r0 = fma(-fn, P1, x);           // exact
+  const double r = fma(-fn, P2, r0);           // head of the reduced argument
+  double t = fma(-fn, P2, r0 - r);             // what the rounding of r dropped
+  t = fma(-fn, P3, t);                         // tail
+  const double z = r * r;
+  double rs = fma(z, S6, S5);
+  rs = fma(z, rs, S4);
+  rs = fma(z, rs, S3);
+  rs = fma(z, rs, S2);
+  const double v = z * r;
+  // r - ((z (t/2 - v rs) - t) - v S1)
+  const double sn = r - (fma(z, fma(0.5, t, -(v * rs)), -t) - v * S1);
+  double rc = fma(z, C6, C5);
+  rc = fma(z, rc, C4);
+  rc = fma(z, rc, C3);
+  rc = fma(z, rc, C2);
+  rc = fma(z, rc, C1);
+  const double hz = 0.5 * z;
+  const double w = 1.0 - hz;
+  const double cs = w + (((1.0 - w) - hz) + fma(z * z, rc, -(r * t)));
+  const int q = (int)fn & 3;
+  const double a = (q & 1) ? cs : sn;
+  const double b = (q & 1) ? sn : cs;
+  s = (q & 2) ? -a : a;
+  c = ((q + 1) & 2) ? -b : b;
+}
+
+// x / 1.1f in binary32, correctly rounded, without a hardware divide: with
+// y = RN(1 / c), q = RN(x y) is within an ulp of x / c, r = x - q c is exact in
+// one fma, and RN(q + r y) is the correctly rounded quotient (Markstein) as
+// long as nothing over/underflows.  Valid for 2^-100 <= |x| <= 2^100; callers
+// fall back to a true divide outside.  Checked against `x / 1.1f` for every
+// float in that range by tests/host_math_check.cpp.
+GX_HD float div_by_total_mass(float x) {
+  const float c = 1.0f + 0.1f;
+  const float y = 1.0f / c;
+  const float q = x * y;
+  const float r = fmaf(-q, c, x);
+  return fmaf(r, y, q);
+}
+GX_HD bool div_fast_range(float x) {
+  const float a = fabsf(x);
+  return a >= 0x1.0p-100f && a <= 0x1.0p100f;
+}
+
+}  // namespace math
+}  // namespace gx

@@ -1,0 +1,95 @@
+// Trigonometry policies of the continuous-control kernels.
+//
+// MODE  EXACT : Math.Sin/Cos/Atan2 of the C# source take and return double and
+//               the source casts the result to float, which rounds once; the
+//               kernels do the same in binary64.
+//       FAST32: binary32 device trig with identities applied.
+// BOUNDED     : the caller guarantees the angle ranges stated at each function
+//               (the host selects it only when the env's invariants hold), so
+//               the reduction-light routines of gx_math.h replace the
+//               full-range library ones.  Both are accurate to the last place
+//               of the double; the float results differ from each other (and
+//               from glibc's) only when the true value sits within ~2^-29 of a
+//               float rounding boundary.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/gymx.h"
+#include "gx_math.h"
+
+namespace gx {
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+template <int MODE, bool BOUNDED>
+struct Trig;
+
+template <>
+struct Trig<GX_MODE_EXACT, false> {
+  // |x| <= pi/4 promised only by the BOUNDED variant; here any float
+  static __device__ __forceinline__ void sincos_quarter(float x, float& s, float& c) { sincos(x, s, c); }
+  static __device__ __forceinline__ void sincos(float x, float& s, float& c) {
+    double sd, cd;
+    ::sincos((double)x, &sd, &cd);
+    s = (float)sd;
+    c = (float)cd;
+  }
+  static __device__ __forceinline__ float cos(float x) { return (float)::cos((double)x); }
+  // (float)Math.Cos(x - Math.PI / 2.0) with x a float: the subtraction is in double
+  static __device__ __forceinline__ float cos_minus_half_pi(float x) { return (float)::cos((double)x - M_PI / 2.0); }
+  // (float)Math.Sin(x + Math.PI)
+  static __device__ __forceinline__ float sin_plus_pi(float x) { return (float)::sin((double)x + M_PI); }
+  static __device__ __forceinline__ float atan2(float y, float x) { return (float)::atan2((double)y, (double)x); }
+};
+
+template <>
+struct Trig<GX_MODE_EXACT, true> {
+  // requires |x| <= pi/4
+  static __device__ __forceinline__ void sincos_quarter(float x, float& s, float& c) {
+    double sd, cd;
+    math::sincos_small((double)x, sd, cd);
+    s = (float)sd;
+    c = (float)cd;
+  }
+  // the functions below require |argument| below a few thousand
+  static __device__ __forceinline__ void sincos(float x, float& s, float& c) {
+    double sd, cd;
+    math::sincos_bounded((double)x, sd, cd);
+    s = (float)sd;
+    c = (float)cd;
+  }
+  static __device__ __forceinline__ float cos(float x) {
+    double sd, cd;
+    math::sincos_bounded((double)x, sd, cd);
+    return (float)cd;
+  }
+  static __device__ __forceinline__ float cos_minus_half_pi(float x) {
+    double sd, cd;
+    math::sincos_bounded((double)x - M_PI / 2.0, sd, cd);
+    return (float)cd;
+  }
+  static __device__ __forceinline__ float sin_plus_pi(float x) {
+    double sd, cd;
+    math::sincos_bounded((double)x + M_PI, sd, cd);
+    return (float)sd;
+  }
+  static __device__ __forceinline__ float atan2(float y, float x) { return (float)::atan2((double)y, (double)x); }
+};
+
+template <bool BOUNDED>
+struct Trig<GX_MODE_FAST32, BOUNDED> {
+  static __device__ __forceinline__ void sincos_quarter(float x, float& s, float& c) { ::sincosf(x, &s, &c); }
+  static __device__ __forceinline__ void sincos(float x, float& s, float& c) { ::sincosf(x, &s, &c); }
+  static __device__ __forceinline__ float cos(float x) { return ::cosf(x); }
+  static __device__ __forceinline__ float cos_minus_half_pi(float x) { return ::sinf(x); }
+  static __device__ __forceinline__ float sin_plus_pi(float x) { return -::sinf(x); }
+  static __device__ __forceinline__ float atan2(float y, float x) { return ::atan2f(y, x); }
+};
+
+// Math.Clamp(float, float, float)
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+}  // namespace gx

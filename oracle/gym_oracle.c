@@ -39,10 +39,10 @@
  * (Envs.CartPole.cs:19, Spaces.Box.cs:14, Spaces.Discrete.cs:11) and
  * Env.Seed is an empty virtual (Env.cs:33-36), so its draws cannot be
  * reproduced.  The build defines instead
- *     x   = Philox4x32-10(key = seed, ctr = (env_lo, env_hi, tick_lo,
- *                         stream<<24 | tick_hi8<<16 | block))
- *     u64 = words (1:0) for even draws, (3:2) for odd draws, block = draw/2
- *     u   = (u64 >> 11) * 2^-53  in [0,1)
+ *     w = word (draw & 3) of Philox4x32-10(key = seed, ctr = (env_lo, env_hi,
+ *               tick_lo, stream<<24 | tick_hi8<<16 | draw>>2))
+ *     u = w * 2^-32  in [0,1)            (NextDouble stand-in, 32 random bits)
+ *     k = (w * n) >> 32  in [0,n)        (Next(n) stand-in)
  * with `tick` = number of Reset()/Step() calls made on the batch before the
  * one that consumes the draw.  Streams: 0 = Reset draws, 1 = draws an env
  * makes inside Step, 2 = action-space samples of the random policy.
@@ -64,27 +64,27 @@ void gxo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-uint64_t gxo_rng_u64(uint64_t seed, uint64_t env_index, uint64_t tick, uint32_t stream, uint32_t draw) {
+uint32_t gxo_rng_u32(uint64_t seed, uint64_t env_index, uint64_t tick, uint32_t stream, uint32_t draw) {
   uint32_t ctr[4], key[2], out[4];
   ctr[0] = (uint32_t)env_index;
   ctr[1] = (uint32_t)(env_index >> 32);
   ctr[2] = (uint32_t)tick;
-  ctr[3] = (stream << 24) | ((uint32_t)((tick >> 32) & 0xFFu) << 16) | ((draw >> 1) & 0xFFFFu);
+  ctr[3] = (stream << 24) | ((uint32_t)((tick >> 32) & 0xFFu) << 16) | ((draw >> 2) & 0xFFFFu);
   key[0] = (uint32_t)seed;
   key[1] = (uint32_t)(seed >> 32);
   gxo_philox4x32_10(ctr, key, out);
-  return (draw & 1u) ? (((uint64_t)out[3] << 32) | out[2]) : (((uint64_t)out[1] << 32) | out[0]);
+  return out[draw & 3u];
 }
 
 double gxo_rng_uniform(uint64_t seed, uint64_t env_index, uint64_t tick, uint32_t stream, uint32_t draw) {
-  return (double)(gxo_rng_u64(seed, env_index, tick, stream, draw) >> 11) * 0x1.0p-53;
+  return (double)gxo_rng_u32(seed, env_index, tick, stream, draw) * 0x1.0p-32;
 }
 
-/* Random.Next(n) stand-in (Spaces.Discrete.cs:18, Envs.Taxi.cs:20): the high
- * 32 bits of the draw scaled into [0,n) by multiply-shift. */
+/* Random.Next(n) stand-in (Spaces.Discrete.cs:18, Envs.Taxi.cs:20): the draw
+ * scaled into [0,n) by multiply-shift. */
 int32_t gxo_rng_below(uint64_t seed, uint64_t env_index, uint64_t tick, uint32_t stream, uint32_t draw, int32_t n) {
-  uint64_t hi = gxo_rng_u64(seed, env_index, tick, stream, draw) >> 32;
-  return (int32_t)((hi * (uint64_t)(uint32_t)n) >> 32);
+  uint64_t w = gxo_rng_u32(seed, env_index, tick, stream, draw);
+  return (int32_t)((w * (uint64_t)(uint32_t)n) >> 32);
 }
 
 /* Spaces.Box.cs:30 -- `(float)(NextDouble() * (High[i] - Low[i]) + Low[i])`:

@@ -68,7 +68,7 @@ typedef struct gxo_stats {
 
 /* ---- counter RNG (build-defined; the reference's System.Random is unseeded) */
 void gxo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
-uint64_t gxo_rng_u64(uint64_t seed, uint64_t env_index, uint64_t tick, uint32_t stream, uint32_t draw);
+uint32_t gxo_rng_u32(uint64_t seed, uint64_t env_index, uint64_t tick, uint32_t stream, uint32_t draw);
 double gxo_rng_uniform(uint64_t seed, uint64_t env_index, uint64_t tick, uint32_t stream, uint32_t draw);
 int32_t gxo_rng_below(uint64_t seed, uint64_t env_index, uint64_t tick, uint32_t stream, uint32_t draw, int32_t n);
 

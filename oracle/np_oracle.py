@@ -42,23 +42,22 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
     return c0, c1, c2, c3
 
 
-def rng_u64(seed, env, tick, stream, draw):
+def rng_u32(seed, env, tick, stream, draw):
+    """word (draw & 3) of the Philox block (draw >> 2) of this (env, tick, stream)"""
     env = np.asarray(env, np.uint64)
     tick = int(tick)
-    c3 = np.uint64((stream << 24) | (((tick >> 32) & 0xFF) << 16) | ((draw >> 1) & 0xFFFF))
+    c3 = np.uint64((stream << 24) | (((tick >> 32) & 0xFF) << 16) | ((draw >> 2) & 0xFFFF))
     o = philox4x32_10(env & M32, env >> np.uint64(32), np.full_like(env, tick & 0xFFFFFFFF),
                       np.full_like(env, c3), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
-    lo, hi = (o[2], o[3]) if (draw & 1) else (o[0], o[1])
-    return (hi << np.uint64(32)) | lo
+    return o[draw & 3]
 
 
 def rng_uniform(seed, env, tick, stream, draw):
-    return (rng_u64(seed, env, tick, stream, draw) >> np.uint64(11)).astype(f64) * 2.0 ** -53
+    return rng_u32(seed, env, tick, stream, draw).astype(f64) * 2.0 ** -32
 
 
 def rng_below(seed, env, tick, stream, draw, n):
-    hi = rng_u64(seed, env, tick, stream, draw) >> np.uint64(32)
-    return ((hi * np.uint64(n)) >> np.uint64(32)).astype(np.int32)
+    return ((rng_u32(seed, env, tick, stream, draw) * np.uint64(n)) >> np.uint64(32)).astype(np.int32)
 
 
 # -------------------------------------------------------------- libm helpers

@@ -46,13 +46,16 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(_SO):
-        build()
+    try:
+        build()  # no-op when the shared object is newer than its sources
+    except (OSError, subprocess.CalledProcessError):
+        if not os.path.exists(_SO):
+            raise
     L = C.CDLL(_SO)
     vp, u64, u32, i32, dbl = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32, C.c_double
     L.gxo_philox4x32_10.argtypes = [vp, vp, vp]
-    L.gxo_rng_u64.restype = u64
-    L.gxo_rng_u64.argtypes = [u64, u64, u64, u32, u32]
+    L.gxo_rng_u32.restype = u32
+    L.gxo_rng_u32.argtypes = [u64, u64, u64, u32, u32]
     L.gxo_rng_uniform.restype = dbl
     L.gxo_rng_uniform.argtypes = [u64, u64, u64, u32, u32]
     L.gxo_rng_below.restype = i32
@@ -205,8 +208,8 @@ def philox(ctr, key):
     return [int(x) for x in o]
 
 
-def rng_u64(seed, env, tick, stream, draw):
-    return lib().gxo_rng_u64(seed, env, tick, stream, draw)
+def rng_u32(seed, env, tick, stream, draw):
+    return lib().gxo_rng_u32(seed, env, tick, stream, draw)
 
 
 def rng_uniform(seed, env, tick, stream, draw):

@@ -1,0 +1,71 @@
+// Host-side check of gym_amd/csrc/gx_math.h against the platform libm (the
+// same header compiles for the device).  Build: g++ -O2 -ffp-contract=off
+// -mfma tests/host_math_check.cpp -o ... ; run: ./host_math_check [stride]
+//   sincos_small: (float)sin / (float)cos of every `stride`-th float in
+//                 [-pi/4, pi/4] against (float)sin((double)x), (float)cos(...)
+//   sincos_bounded: floats in [-16, 16] and their shifts by -pi/2 and +pi, the same way
+//   div_by_total_mass: every `stride`-th float in [2^-100, 2^100], both signs,
+//                 against x / 1.1f
+// Prints the mismatch counts; exit status 0 when both are within bounds.
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../gym_amd/csrc/gx_math.h"
+
+static float from_bits(uint32_t b) { float f; std::memcpy(&f, &b, 4); return f; }
+static uint32_t to_bits(float f) { uint32_t b; std::memcpy(&b, &f, 4); return b; }
+
+int main(int argc, char** argv) {
+  const uint32_t stride = argc > 1 ? (uint32_t)std::atoi(argv[1]) : 64;
+  // ---- sincos_small
+  const uint32_t hi = to_bits(0.78539816f);
+  unsigned long long n = 0, bad_s = 0, bad_c = 0;
+  for (uint32_t sign = 0; sign < 2; sign++)
+    for (uint32_t b = 0; b <= hi; b += stride) {
+      const float x = from_bits(b | (sign << 31));
+      double s, c;
+      gx::math::sincos_small((double)x, s, c);
+      const float fs = (float)s, fc = (float)c;
+      const float rs = (float)std::sin((double)x), rc = (float)std::cos((double)x);
+      n++;
+      bad_s += to_bits(fs) != to_bits(rs);
+      bad_c += to_bits(fc) != to_bits(rc);
+    }
+  std::printf("sincos_small: %llu inputs, sin mismatches %llu, cos mismatches %llu\n", n, bad_s, bad_c);
+  // ---- sincos_bounded: floats |x| <= 16, and the shifted arguments the dynamics form
+  // ((double)x - pi/2 and (double)x + pi)
+  const uint32_t hi16 = to_bits(16.0f);
+  unsigned long long nb = 0, bad_b = 0;
+  for (uint32_t sign = 0; sign < 2; sign++)
+    for (uint32_t b = 0; b <= hi16; b += stride * 3 + 1) {
+      const float x = from_bits(b | (sign << 31));
+      const double args[3] = {(double)x, (double)x - M_PI / 2.0, (double)x + M_PI};
+      for (int k = 0; k < 3; k++) {
+        double s, c;
+        gx::math::sincos_bounded(args[k], s, c);
+        nb += 2;
+        bad_b += to_bits((float)s) != to_bits((float)std::sin(args[k]));
+        bad_b += to_bits((float)c) != to_bits((float)std::cos(args[k]));
+      }
+    }
+  std::printf("sincos_bounded: %llu results, mismatches %llu\n", nb, bad_b);
+  // ---- division by 1.1f
+  const float c11 = 1.0f + 0.1f;
+  unsigned long long nd = 0, bad_d = 0;
+  const uint32_t lo_b = to_bits(0x1.0p-100f), hi_b = to_bits(0x1.0p100f);
+  for (uint32_t sign = 0; sign < 2; sign++)
+    for (uint32_t b = lo_b; b <= hi_b; b += stride) {
+      const float x = from_bits(b | (sign << 31));
+      volatile float q_ref = x / c11;
+      const float q = gx::math::div_by_total_mass(x);
+      nd++;
+      bad_d += to_bits(q) != to_bits(q_ref);
+    }
+  std::printf("div_by_total_mass: %llu inputs, mismatches %llu\n", nd, bad_d);
+  // one rounding-boundary event per ~2^28 trig calls is expected; the division must be exact
+  const bool ok = bad_d == 0 && bad_b * (1ull << 24) <= nb + (1ull << 24) && bad_s * (1ull << 24) <= n + (1ull << 24) && bad_c * (1ull << 24) <= n + (1ull << 24);
+  return ok ? 0 : 1;
+}
