@@ -167,8 +167,21 @@ def main():
         },
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                     "kernel_ms": kernel_ms, "bytes_per_env_step": b_alg},
+                     "kernel_ms": kernel_ms, "bytes_per_env_step": b_alg,
+                     "algorithmic_bytes_per_launch": b_alg * n},
     }
+    # HBM bytes per launch from the rocprofv3 counter passes (FETCH_SIZE doubled as gfx950
+    # needs, WRITE_SIZE as read) of this same command, taken by tools/collect_profiles.sh and
+    # committed under profiles/; counters cannot be read from inside this process.
+    traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(traffic_file) and world == 1:
+        try:
+            t = json.load(open(traffic_file)).get("%s:%d:%s" % (args.env, n, args.policy))
+            if t:
+                out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = t["source"]
+        except (OSError, ValueError, KeyError):
+            pass
 
     # episode statistics: device reduction, then one RCCL all-reduce across ranks
     s = batch.stats()

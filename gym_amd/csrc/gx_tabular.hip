@@ -25,6 +25,11 @@ __device__ __forceinline__ void store4i(int32_t* base, uint64_t quad, const int3
 __device__ __forceinline__ void store4f(float* base, uint64_t quad, const float (&in)[4]) {
   reinterpret_cast<float4*>(base)[quad] = make_float4(in[0], in[1], in[2], in[3]);
 }
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store4f_nt(float* base, uint64_t quad, const float (&in)[4]) {
+  f32x4 v = {in[0], in[1], in[2], in[3]};
+  __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(base) + quad);
+}
 __device__ __forceinline__ uint32_t pack4(const bool (&b)[4]) {
   return (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
 }
@@ -62,7 +67,9 @@ __global__ void __launch_bounds__(kBlock) tabular_step_kernel(StepArgs a) {
   StatAcc acc;
 
   const uint64_t nquads = (a.num_envs + 3) >> 2;
-  for (uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q < nquads; q += (uint64_t)gridDim.x * kBlock) {
+  for (uint64_t it = (uint64_t)blockIdx.x * kBlock + threadIdx.x; it < nquads; it += (uint64_t)gridDim.x * kBlock) {
+    // alternate launches sweep in opposite directions (memory-side cache reuse across steps)
+    const uint64_t q = a.reverse ? nquads - 1 - it : it;
     int32_t st[4], steps[4], ep_ret[4] = {}, ep_len[4] = {};
     load4i(state_row, q, st);
     load4i(steps_row, q, steps);
@@ -116,9 +123,10 @@ __global__ void __launch_bounds__(kBlock) tabular_step_kernel(StepArgs a) {
       store4i(static_cast<int32_t*>(a.ep_return), q, ep_ret);
       if (a.ep_length) store4i(a.ep_length, q, ep_len);
     }
-    store4f(static_cast<float*>(a.reward), q, reward);
-    reinterpret_cast<uint32_t*>(a.done)[q] = pack4(done);
-    if (a.truncated) reinterpret_cast<uint32_t*>(a.truncated)[q] = pack4(trunc);
+    // write-only rows stream past the caches
+    store4f_nt(static_cast<float*>(a.reward), q, reward);
+    __builtin_nontemporal_store(pack4(done), reinterpret_cast<uint32_t*>(a.done) + q);
+    if (a.truncated) __builtin_nontemporal_store(pack4(trunc), reinterpret_cast<uint32_t*>(a.truncated) + q);
   }
   if (record) block_commit_stats(acc, a.stat_slots);
 }
@@ -132,7 +140,9 @@ __global__ void __launch_bounds__(kBlock) dummy_step_kernel(StepArgs a) {
   int32_t* const steps_row = a.state_int + a.stride;
   StatAcc acc;
   const uint64_t nquads = (a.num_envs + 3) >> 2;
-  for (uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q < nquads; q += (uint64_t)gridDim.x * kBlock) {
+  for (uint64_t it = (uint64_t)blockIdx.x * kBlock + threadIdx.x; it < nquads; it += (uint64_t)gridDim.x * kBlock) {
+    // alternate launches sweep in opposite directions (memory-side cache reuse across steps)
+    const uint64_t q = a.reverse ? nquads - 1 - it : it;
     int32_t st[4], steps[4], ep_ret[4] = {}, ep_len[4] = {};
     load4i(state_row, q, st);
     load4i(steps_row, q, steps);
@@ -180,9 +190,10 @@ __global__ void __launch_bounds__(kBlock) dummy_step_kernel(StepArgs a) {
       store4i(static_cast<int32_t*>(a.ep_return), q, ep_ret);
       if (a.ep_length) store4i(a.ep_length, q, ep_len);
     }
-    store4f(static_cast<float*>(a.reward), q, reward);
-    reinterpret_cast<uint32_t*>(a.done)[q] = pack4(done);
-    if (a.truncated) reinterpret_cast<uint32_t*>(a.truncated)[q] = pack4(trunc);
+    // write-only rows stream past the caches
+    store4f_nt(static_cast<float*>(a.reward), q, reward);
+    __builtin_nontemporal_store(pack4(done), reinterpret_cast<uint32_t*>(a.done) + q);
+    if (a.truncated) __builtin_nontemporal_store(pack4(trunc), reinterpret_cast<uint32_t*>(a.truncated) + q);
   }
   if (record) block_commit_stats(acc, a.stat_slots);
 }
