@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402  (device memory, streams, events, torch.distributed only)
 
 from gym_amd import _lib as L  # noqa: E402
+from gym_amd.distributed import allreduce_stats, shard  # noqa: E402
 from gym_amd.engine import Context, DeviceBatch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0       # MI355X HBM3E peak
@@ -135,8 +136,11 @@ def main():
     ctx = Context(local_rank)
     flags = L.AUTORESET | L.RECORD_STATS
     mode = L.MODE_EXACT if args.mode == "exact" else L.MODE_FAST32
+    # weak scaling: every rank owns n envs of the n * world batch, keyed by global env index
+    base, n_local = shard(n * world, rank, world)
+    assert n_local == n
     batch = DeviceBatch(ctx, ENV_IDS[args.env], n, seed=0x9E3779B97F4A7C15, flags=flags, mode=mode,
-                        env_index_base=rank * n)
+                        env_index_base=base)
     batch.reset()
     stream_ptr = torch.cuda.current_stream().cuda_stream
     view = batch.view()
@@ -184,12 +188,10 @@ def main():
             pass
 
     # episode statistics: device reduction, then one RCCL all-reduce across ranks
-    s = batch.stats()
-    st = torch.tensor([float(s.episodes), float(s.sum_length), s.sum_return], dtype=torch.float64, device="cuda")
-    if dist is not None:
-        dist.all_reduce(st, op=dist.ReduceOp.SUM)
-    ep = st.tolist()
-    out["episode_stats"] = {"episodes": int(ep[0]), "mean_length": ep[1] / max(ep[0], 1), "mean_return": ep[2] / max(ep[0], 1)}
+    ep = allreduce_stats(batch.stats(), dist, device="cuda")
+    out["episode_stats"] = {"episodes": ep["episodes"], "mean_length": ep["sum_length"] / max(ep["episodes"], 1),
+                            "mean_return": ep["sum_return"] / max(ep["episodes"], 1),
+                            "min_return": ep["min_return"], "max_return": ep["max_return"]}
 
     if rank == 0 and world == 1 and not args.no_extra and args.env == "cartpole":
         out["extra"] = extra_measurements(ctx, n, stream_ptr)

@@ -1,3 +1,15 @@
 """MI355X-native batched environment engine behind the API surface of the C#
 Gymnasium port (Env / VectorEnv / EnvRegistry / Spaces)."""
-from . import _lib  # noqa: F401
+from . import spaces
+from .env import (ActionWrapper, Env, EnvWrapper, ObservationWrapper, RecordEpisodeStatistics, RewardWrapper,
+                  TimeLimit)
+from .envs import (Acrobot, CartPole, CliffWalking, DummyEnv, FrozenLake, MountainCar, MountainCarContinuous,
+                   Pendulum, Pong, Taxi)
+from .registry import EnvRegistry, RegisterAll
+from .spaces import Box, Discrete
+from .vector_env import VectorEnv
+
+__all__ = ["spaces", "Env", "EnvWrapper", "ObservationWrapper", "ActionWrapper", "RewardWrapper",
+           "RecordEpisodeStatistics", "TimeLimit", "CartPole", "MountainCar", "MountainCarContinuous", "Pendulum",
+           "Acrobot", "FrozenLake", "Taxi", "CliffWalking", "Pong", "DummyEnv", "EnvRegistry", "RegisterAll", "Box",
+           "Discrete", "VectorEnv"]

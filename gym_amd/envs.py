@@ -1,0 +1,230 @@
+"""The environments of the device path as Env objects (Gymnasium/Envs.*.cs).
+
+Every instance is backed by a device-resident batch of one env: Reset/Step
+launch the same kernels VectorEnv uses, there is no host implementation of any
+dynamics.  Constructing an env needs no GPU; the first Reset()/Step() does.
+"""
+import numpy as np
+
+from . import _lib as L
+from .env import Env
+from .spaces import Box, Discrete
+
+_contexts = {}
+
+
+def default_context(device=0):
+    from .engine import Context
+
+    if device not in _contexts:
+        _contexts[device] = Context(device)
+    return _contexts[device]
+
+
+class DeviceEnv(Env):
+    """Base of the device-backed envs; subclasses set ENV_ID, spaces and the state shape."""
+
+    ENV_ID = None
+    ID = None
+
+    def __init__(self, seed=0, device=0, mode=L.MODE_EXACT, flags=0, map_rows=None):
+        self._seed = seed
+        self._device = device
+        self._mode = mode
+        self._flags = flags
+        self._map_rows = map_rows
+        self._batch = None
+
+    # -- engine plumbing -------------------------------------------------
+    def _ensure(self):
+        if self._batch is None:
+            from .engine import DeviceBatch
+
+            self._batch = DeviceBatch(default_context(self._device), self.ENV_ID, 1, seed=self._seed, mode=self._mode,
+                                      flags=self._flags, map_rows=self._map_rows)
+        return self._batch
+
+    def batch_config(self):
+        """what VectorEnv needs to build one batch for a list of these envs"""
+        return dict(env_id=self.ENV_ID, seed=self._seed, mode=self._mode, flags=self._flags, map_rows=self._map_rows,
+                    device=self._device)
+
+    def _state_of(self, obs, index=0):
+        """observation arrays of a batch -> the reference's TState for env `index`"""
+        raise NotImplementedError
+
+    def _info(self, batch, index=0):
+        return {}
+
+    # -- Env ---------------------------------------------------------------
+    def Seed(self, seed=None):
+        """Extension: the reference's Seed is empty (Env.cs:33-36); here it re-keys the counter RNG."""
+        if seed is not None:
+            self._seed = int(seed)
+            if self._batch is not None:
+                self._batch.close()
+                self._batch = None
+
+    def Reset(self):
+        b = self._ensure()
+        b.reset()
+        return self._state_of(b.get_obs())
+
+    def Step(self, action):
+        b = self._ensure()
+        obs, reward, done, _ = b.step_host(np.array([action], b.action_dtype), want_obs=True)
+        return self._state_of(obs), float(reward[0]), bool(done[0]), self._info(b)
+
+    def Render(self, mode="human"):
+        print("State: %s" % (self._state_of(self._ensure().get_obs()),))
+
+    def Close(self):
+        if self._batch is not None:
+            self._batch.close()
+            self._batch = None
+
+
+class _TupleStateEnv(DeviceEnv):
+    def _state_of(self, obs, index=0):
+        return tuple(float(x) for x in obs[:, index])
+
+
+class _ArrayStateEnv(DeviceEnv):
+    def _state_of(self, obs, index=0):
+        # a fresh array per call: the reference hands out its internal array (Envs.Pendulum.cs:59)
+        return np.array(obs[:, index], np.float32)
+
+
+class _IntStateEnv(DeviceEnv):
+    def _state_of(self, obs, index=0):
+        return int(obs[index])
+
+
+class CartPole(_TupleStateEnv):
+    """Envs.CartPole.cs:10-83: Env<(float,float,float,float), int>"""
+    ENV_ID, ID = L.ENV_CARTPOLE, "CartPole-v1"
+
+    def __init__(self, **kw):
+        super().__init__(**kw)
+        self.ActionSpace = Discrete(2)
+        self.ObservationSpace = Box([-2.4, -3.0, -0.2095, -3.0], [2.4, 3.0, 0.2095, 3.0])
+
+
+class MountainCar(_TupleStateEnv):
+    """Envs.MountainCar.cs:10-58: Env<(float,float), int>"""
+    ENV_ID, ID = L.ENV_MOUNTAINCAR, "MountainCar-v0"
+
+    def __init__(self, **kw):
+        super().__init__(**kw)
+        self.ActionSpace = Discrete(3)
+        self.ObservationSpace = Box([-1.2, -0.07], [0.6, 0.07])
+
+
+class MountainCarContinuous(_TupleStateEnv):
+    """Envs.MountainCarContinuous.cs:10-57: Env<(float,float), float>"""
+    ENV_ID, ID = L.ENV_MOUNTAINCAR_CONT, "MountainCarContinuous-v0"
+
+    def __init__(self, **kw):
+        super().__init__(**kw)
+        self.ActionSpace = Box([-1.0], [1.0])
+        self.ObservationSpace = Box([-1.2, -0.07], [0.6, 0.07])
+
+
+class Pendulum(_ArrayStateEnv):
+    """Envs.Pendulum.cs:10-68: Env<float[], float>"""
+    ENV_ID, ID = L.ENV_PENDULUM, "Pendulum-v1"
+
+    def __init__(self, **kw):
+        super().__init__(**kw)
+        self.ActionSpace = Box([-2.0], [2.0])
+        self.ObservationSpace = Box([-1.0, -1.0, -8.0], [1.0, 1.0, 8.0])
+
+
+class Acrobot(_ArrayStateEnv):
+    """Envs.Acrobot.cs:10-99: Env<float[], int>"""
+    ENV_ID, ID = L.ENV_ACROBOT, "Acrobot-v1"
+
+    def __init__(self, **kw):
+        super().__init__(**kw)
+        self.ActionSpace = Discrete(3)
+        self.ObservationSpace = Box([-1, -1, -1, -1, -6, -6], [1, 1, 1, 1, 6, 6])
+
+    def Step(self, action):
+        try:
+            return super().Step(action)
+        except L.GymxError as e:
+            if e.code == L.GX_ERR_INVALID:
+                raise IndexError(str(e))  # IndexOutOfRangeException, Envs.Acrobot.cs:51
+            raise
+
+
+class FrozenLake(_IntStateEnv):
+    """Envs.FrozenLake.cs:10-88: Env<int,int>; `map` as the constructor argument (:23)"""
+    ENV_ID, ID = L.ENV_FROZENLAKE, "FrozenLake-v1"
+
+    def __init__(self, map=None, **kw):
+        super().__init__(map_rows=list(map) if map is not None else None, **kw)
+        rows = list(map) if map is not None else ["SFFF", "FHFH", "FFFH", "HFFG"]
+        self.ActionSpace = Discrete(4)
+        self.ObservationSpace = Discrete(len(rows) * len(rows[0]))
+
+
+class Taxi(_IntStateEnv):
+    """Envs.Taxi.cs:10-41 (a stub in the reference: the state never changes)"""
+    ENV_ID, ID = L.ENV_TAXI, "Taxi-v3"
+
+    def __init__(self, **kw):
+        super().__init__(**kw)
+        self.ActionSpace = Discrete(6)
+        self.ObservationSpace = Discrete(500)
+
+
+class CliffWalking(_IntStateEnv):
+    """Envs.CliffWalking.cs:10-77"""
+    ENV_ID, ID = L.ENV_CLIFFWALKING, "CliffWalking-v0"
+
+    def __init__(self, **kw):
+        super().__init__(**kw)
+        self.ActionSpace = Discrete(4)
+        self.ObservationSpace = Discrete(48)
+
+
+class Pong(DeviceEnv):
+    """Envs.Pong.cs:12-266: Env<byte[], int>; the observation is the 210x160x3 frame"""
+    ENV_ID, ID = L.ENV_PONG, "Pong-v4"
+    FRAME = 210 * 160 * 3
+
+    def __init__(self, **kw):
+        super().__init__(**kw)
+        self.ActionSpace = Discrete(4)
+        self.ObservationSpace = Box(np.zeros(self.FRAME, np.float32), np.full(self.FRAME, 255.0, np.float32))
+
+    @property
+    def Spec(self):
+        return {"id": "Pong-v4", "max_episode_steps": 1000}  # Envs.Pong.cs:43
+
+    @property
+    def Metadata(self):
+        return {"render_modes": ["human", "rgb_array"]}
+
+    @property
+    def RewardRange(self):
+        return (-1, 1)
+
+    def _state_of(self, obs, index=0):
+        return np.array(obs[index], np.uint8)
+
+    def _info(self, batch, index=0):
+        reals, ints = batch.get_state()  # Envs.Pong.cs:148-154
+        return {"left_score": int(ints[0, index]), "right_score": int(ints[1, index]),
+                "ball_x": float(reals[0, index]), "ball_y": float(reals[1, index])}
+
+
+class DummyEnv(_IntStateEnv):
+    """DummyEnv.cs:10-38"""
+    ENV_ID, ID = L.ENV_DUMMY, "Dummy"
+
+    def __init__(self, **kw):
+        super().__init__(**kw)
+        self.ActionSpace = Discrete(3)
+        self.ObservationSpace = Discrete(20)

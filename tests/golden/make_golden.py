@@ -1,0 +1,59 @@
+"""Generates tests/golden/*.npz from the CPU oracle (oracle/gym_oracle.c).
+
+The reference is C# and cannot run here, and its own tests hold no numeric vectors for these
+envs, so these fixtures are outputs of the oracle (itself pinned by hand-derived known answers
+and by the independent numpy restatement).  Per env: 256 start states x 64 steps of random
+actions -- initial SoA state, the actions, every reward / done flag and the final state; for
+Pong additionally 8 frames as bit masks (a frame is 0/255 with equal channels).
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle import oracle as O  # noqa: E402
+
+N, T, SEED = 256, 64, 20250614
+CASES = [
+    ("cartpole", O.CARTPOLE, 2, {}), ("mountaincar", O.MOUNTAINCAR, 3, {}), ("mountaincar_cont", O.MOUNTAINCAR_CONT, None, {}),
+    ("pendulum", O.PENDULUM, None, {}), ("acrobot", O.ACROBOT, 3, {}), ("frozenlake", O.FROZENLAKE, 4, {}),
+    ("frozenlake_8x8", O.FROZENLAKE, 4, {"map_rows": ["SFFFFFFF", "FFFFFFFF", "FFFHFFFF", "FFFFFHFF", "FFFHFFFF", "FHHFFFHF", "FHFFHFHF", "FFFHFFFG"]}),
+    ("taxi", O.TAXI, 6, {}), ("cliffwalking", O.CLIFFWALKING, 4, {}), ("pong", O.PONG, 4, {}),
+]
+
+
+def main():
+    for name, eid, nact, kw in CASES:
+        rng = np.random.default_rng(sum(map(ord, name)))
+        steps = 400 if name == "pong" else T
+        v = O.OracleVec(eid, N, seed=SEED, **kw)
+        v.reset()
+        init = v.get_state_raw().copy()
+        if nact is None:
+            actions = (rng.random((steps, N)) * 5 - 2.5).astype(np.float32)
+        else:
+            actions = rng.integers(0, nact, (steps, N)).astype(np.int32)
+        rewards = np.empty((steps, N), np.float64)
+        dones = np.empty((steps, N), np.uint8)
+        frames = []
+        for t in range(steps):
+            rewards[t], dones[t], _ = v.step(actions[t])
+            if name == "pong" and t % 50 == 49:
+                f = v.get_obs()[:8]
+                assert ((f == 0) | (f == 255)).all() and (f[:, 0::3] == f[:, 1::3]).all() and (f[:, 0::3] == f[:, 2::3]).all()
+                frames.append(np.packbits(f[:, 0::3] == 255, axis=1))
+        out = dict(init=init, actions=actions, rewards=rewards, dones=dones, final=v.get_state_raw(), seed=np.int64(SEED))
+        if kw.get("map_rows"):
+            out["map_rows"] = np.array("/".join(kw["map_rows"]))
+        if frames:
+            out["frame_masks"] = np.stack(frames)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print(name, {k: getattr(x, "shape", None) for k, x in out.items()})
+
+
+if __name__ == "__main__":
+    main()

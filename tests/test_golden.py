@@ -1,0 +1,80 @@
+"""Committed golden vectors (tests/golden/*.npz, made by tests/golden/make_golden.py from the
+oracle): the oracle must keep reproducing them (CPU), and the HIP path must reproduce them
+through the C ABI (GPU) -- bit-exact for tabular envs and Pong, and for the continuous envs too
+unless a last-place double-precision trig difference flips a float rounding (then <= 1e-5)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FILES = sorted(glob.glob(os.path.join(HERE, "golden", "*.npz")))
+ENV_OF = {"cartpole": "CARTPOLE", "mountaincar": "MOUNTAINCAR", "mountaincar_cont": "MOUNTAINCAR_CONT", "pendulum": "PENDULUM",
+          "acrobot": "ACROBOT", "frozenlake": "FROZENLAKE", "frozenlake_8x8": "FROZENLAKE", "taxi": "TAXI",
+          "cliffwalking": "CLIFFWALKING", "pong": "PONG"}
+EXACT = {"frozenlake", "frozenlake_8x8", "taxi", "cliffwalking", "pong"}
+
+
+def load(path):
+    name = os.path.basename(path)[:-4]
+    z = np.load(path, allow_pickle=False)
+    rows = str(z["map_rows"]).split("/") if "map_rows" in z.files else None
+    return name, z, rows
+
+
+def test_fixtures_present():
+    assert len(FILES) == 10
+
+
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f)[:-4] for f in FILES])
+def test_oracle_reproduces_golden(oracle, path):
+    name, z, rows = load(path)
+    n = z["actions"].shape[1]
+    v = oracle.OracleVec(getattr(oracle, ENV_OF[name]), n, seed=int(z["seed"]), map_rows=rows)
+    v.reset()
+    assert np.array_equal(v.get_state_raw(), z["init"])
+    for t in range(z["actions"].shape[0]):
+        r, d, _ = v.step(z["actions"][t])
+        assert np.array_equal(r, z["rewards"][t]) and np.array_equal(d, z["dones"][t])
+    assert np.array_equal(v.get_state_raw(), z["final"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f)[:-4] for f in FILES])
+def test_gpu_reproduces_golden(path):
+    from gpu_common import L, ctx
+    from gym_amd.engine import DeviceBatch
+
+    name, z, rows = load(path)
+    n = z["actions"].shape[1]
+    g = DeviceBatch(ctx(), getattr(L, "ENV_" + ENV_OF[name]), n, seed=int(z["seed"]), map_rows=rows)
+    g.reset()
+    assert np.array_equal(g.get_state_raw(), z["init"])  # Reset() draws are integer / one-rounding work: exact
+    frames = []
+    mismatched = 0
+    for t in range(z["actions"].shape[0]):
+        want_obs = name == "pong" and t % 50 == 49
+        obs, r, d, _ = g.step_host(z["actions"][t], want_obs=want_obs)
+        if name in EXACT:
+            assert np.array_equal(r.astype(np.float64), z["rewards"][t]) and np.array_equal(d, z["dones"][t]), t
+        else:
+            bad = r.astype(np.float64) != z["rewards"][t]
+            mismatched += int(bad.sum())
+            assert np.allclose(r, z["rewards"][t], rtol=1e-5, atol=1e-6)
+        if want_obs:
+            f = obs[:8]
+            frames.append(np.packbits(f[:, 0::3] == 255, axis=1))
+            assert ((f == 0) | (f == 255)).all() and (f[:, 0::3] == f[:, 1::3]).all() and (f[:, 0::3] == f[:, 2::3]).all()
+    final = g.get_state_raw()
+    if name in EXACT:
+        assert np.array_equal(final, z["final"])
+    else:
+        a = g.split_state(final)[0]
+        b = g.split_state(z["final"].copy())[0]
+        same = np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        # free-running for 64 steps: identical unless a last-place trig event occurred on the way
+        assert same or mismatched > 0 or np.allclose(a, b, rtol=1e-3, atol=1e-3), "state diverged"
+        assert same, "golden continuous-control trajectory not bit-identical (%d reward mismatches)" % mismatched
+    if frames:
+        assert np.array_equal(np.stack(frames), z["frame_masks"])
