@@ -1,0 +1,138 @@
+// P/Invoke surface of libgymx.so (include/gymx.h).  Sources only: the build
+// container has no .NET SDK, so these files are written against the header and
+// the C# language reference and are not compiled here.
+//
+// A maintainer adds this folder to Gymnasium.csproj (net8.0, AllowUnsafeBlocks)
+// next to VectorEnv.cs; nothing else in the library changes.
+using System;
+using System.Runtime.InteropServices;
+
+namespace Gymnasium.Gpu;
+
+public enum GxStatus { Ok = 0, Invalid = 1, Hip = 2, Oom = 3, Unsupported = 4, Rccl = 5 }
+
+public enum GxEnvId
+{
+    CartPole = 0, MountainCar = 1, MountainCarContinuous = 2, Pendulum = 3, Acrobot = 4,
+    FrozenLake = 5, Taxi = 6, CliffWalking = 7, Pong = 8, Dummy = 9
+}
+
+public enum GxMode { Exact = 0, Fast32 = 1 }
+
+[Flags]
+public enum GxFlags : uint { None = 0, AutoReset = 1, RecordStats = 2, Slippery = 4, TaxiFull = 8, AcrobotRk4 = 16 }
+
+public enum GxPolicy { DeviceActions = 0, Random = 1 }
+
+public enum GxDType { F32 = 0, F64 = 1, I32 = 2, U8 = 3 }
+
+[StructLayout(LayoutKind.Sequential)]
+public unsafe struct GxDesc
+{
+    public uint StructSize;
+    public int EnvId;
+    public ulong NumEnvs;
+    public ulong Seed;
+    public ulong EnvIndexBase;
+    public int Mode;
+    public uint Flags;
+    public int TimeLimit;
+    public int Reserved;
+    public byte* MapRows; // UTF-8, rows joined by '/', or null
+}
+
+[StructLayout(LayoutKind.Sequential)]
+public struct GxInfo
+{
+    public ulong NumEnvs;
+    public int EnvId, NReal, RealDType, NInt, ObsDim, ObsDType, ActionDType, ActionN;
+    public float ActionLow, ActionHigh;
+    public int RewardDType, ObsIsState;
+    public ulong StateBytes, ObsBytes;
+}
+
+[StructLayout(LayoutKind.Sequential)]
+public struct GxView
+{
+    public ulong NumEnvs, Stride;
+    public IntPtr StateReal, StateInt, Obs, Reward, Done, Truncated;
+}
+
+[StructLayout(LayoutKind.Sequential)]
+public struct GxStats
+{
+    public long Episodes;
+    public double SumReturn;
+    public long SumLength;
+    public double SumReturnSq, MinReturn, MaxReturn;
+}
+
+internal static unsafe partial class Native
+{
+    private const string Lib = "gymx"; // resolves libgymx.so on Linux
+
+    [LibraryImport(Lib)] internal static partial uint gx_version();
+    [LibraryImport(Lib)] internal static partial IntPtr gx_last_error();
+    [LibraryImport(Lib)] internal static partial int gx_device_count(out int count);
+    [LibraryImport(Lib)] internal static partial int gx_ctx_create(int device, out IntPtr ctx);
+    [LibraryImport(Lib)] internal static partial int gx_ctx_destroy(IntPtr ctx);
+    [LibraryImport(Lib)] internal static partial int gx_ctx_synchronize(IntPtr ctx);
+    [LibraryImport(Lib)] internal static partial int gx_ctx_stream(IntPtr ctx, out IntPtr stream);
+    [LibraryImport(Lib)] internal static partial int gx_vec_create(IntPtr ctx, GxDesc* desc, out IntPtr vec);
+    [LibraryImport(Lib)] internal static partial int gx_vec_destroy(IntPtr vec);
+    [LibraryImport(Lib)] internal static partial int gx_vec_info(IntPtr vec, out GxInfo info);
+    [LibraryImport(Lib)] internal static partial int gx_vec_reset(IntPtr vec);
+    [LibraryImport(Lib)] internal static partial int gx_vec_get_state(IntPtr vec, void* hostSoa, nuint bytes);
+    [LibraryImport(Lib)] internal static partial int gx_vec_set_state(IntPtr vec, void* hostSoa, nuint bytes);
+    [LibraryImport(Lib)] internal static partial int gx_vec_get_obs(IntPtr vec, void* hostObs, nuint bytes);
+    [LibraryImport(Lib)] internal static partial int gx_vec_step_async(IntPtr vec, void* hActions, void* hObs, void* hReward, byte* hDone, byte* hTruncated);
+    [LibraryImport(Lib)] internal static partial int gx_vec_wait(IntPtr vec);
+    [LibraryImport(Lib)] internal static partial int gx_vec_step_device(IntPtr vec, IntPtr dActions, IntPtr stream);
+    [LibraryImport(Lib)] internal static partial int gx_vec_step_random(IntPtr vec, IntPtr stream);
+    [LibraryImport(Lib)] internal static partial int gx_vec_device_view(IntPtr vec, out GxView view);
+    [LibraryImport(Lib)] internal static partial int gx_vec_rollout(IntPtr vec, int kSteps, int policy, IntPtr dActions, IntPtr stream);
+    [LibraryImport(Lib)] internal static partial int gx_vec_sample_actions(IntPtr vec, ulong tick, IntPtr dActions, IntPtr stream);
+    [LibraryImport(Lib)] internal static partial int gx_vec_tick(IntPtr vec, out ulong tick);
+    [LibraryImport(Lib)] internal static partial int gx_vec_stats(IntPtr vec, out GxStats stats);
+    [LibraryImport(Lib)] internal static partial int gx_comm_unique_id(byte* id128);
+    [LibraryImport(Lib)] internal static partial int gx_comm_init(IntPtr ctx, byte* id128, int rank, int world, out IntPtr comm);
+    [LibraryImport(Lib)] internal static partial int gx_comm_destroy(IntPtr comm);
+    [LibraryImport(Lib)] internal static partial int gx_stats_allreduce(IntPtr comm, IntPtr vec, out GxStats stats);
+
+    // The reference reports errors as exceptions (EnvRegistry.cs:22,31; Spaces.Box.cs:19;
+    // Envs.Acrobot.cs:51): status codes are turned back into the matching exception types.
+    internal static void Check(int status)
+    {
+        if (status == 0) return;
+        string msg = Marshal.PtrToStringUTF8(gx_last_error()) ?? "gymx error";
+        throw (GxStatus)status switch
+        {
+            GxStatus.Invalid => new ArgumentException(msg),
+            GxStatus.Oom => new OutOfMemoryException(msg),
+            GxStatus.Unsupported => new NotSupportedException(msg),
+            _ => new InvalidOperationException(msg),
+        };
+    }
+}
+
+internal sealed class ContextHandle : SafeHandle
+{
+    public ContextHandle() : base(IntPtr.Zero, true) { }
+    public override bool IsInvalid => handle == IntPtr.Zero;
+    protected override bool ReleaseHandle() => Native.gx_ctx_destroy(handle) == 0;
+    public static ContextHandle Create(int device)
+    {
+        Native.Check(Native.gx_ctx_create(device, out IntPtr p));
+        var h = new ContextHandle();
+        h.SetHandle(p);
+        return h;
+    }
+}
+
+internal sealed class VecHandle : SafeHandle
+{
+    public VecHandle() : base(IntPtr.Zero, true) { }
+    public override bool IsInvalid => handle == IntPtr.Zero;
+    protected override bool ReleaseHandle() => Native.gx_vec_destroy(handle) == 0;
+    internal void Set(IntPtr p) => SetHandle(p);
+}

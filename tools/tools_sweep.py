@@ -1,17 +1,14 @@
-import os, sys, json, subprocess
-env = dict(os.environ)
-def run(extra_env, args):
-    e = dict(env); e.update(extra_env)
-    r = subprocess.run([sys.executable, "bench.py", "--steps", "50", "--warmup", "5", "--no-cpu-baseline", "--no-extra"] + args, env=e, capture_output=True, text=True)
+"""Single-step kernel times of every env at its headline size (for DESIGN.md)."""
+import json, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+def run(args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "50", "--warmup", "5", "--no-cpu-baseline", "--no-extra"] + args, capture_output=True, text=True)
     try:
         j = json.loads(r.stdout.strip().splitlines()[-1])
-        return j["roofline"]["kernel_ms"], j["roofline"]["achieved"]
-    except Exception as ex:
-        return r.stderr[-300:], None
-for blocks in ["512", "1024", "2048", "4096", "8192", "16384", "65536"]:
-    print("grid", blocks, run({"GYMX_GRID_BLOCKS": blocks}, []), flush=True)
-print("fast32", run({}, ["--mode", "fast32"]), flush=True)
-print("random policy", run({}, ["--policy", "random"]), flush=True)
-for envn in ["mountaincar", "pendulum", "acrobot", "frozenlake", "pong"]:
-    print(envn, run({}, ["--env", envn]), flush=True)
-    print(envn, "random", run({}, ["--env", envn, "--policy", "random"]), flush=True)
+        return "%.4f ms  %.3e steps/s  %.0f GB/s (%.1f%% of 8 TB/s)" % (j["roofline"]["kernel_ms"], j["value"], j["roofline"]["achieved"], 100 * j["roofline"]["frac"])
+    except Exception:
+        return r.stderr[-300:]
+for env, n in [("cartpole", 1 << 24), ("mountaincar", 1 << 24), ("pendulum", 1 << 24), ("acrobot", 1 << 24), ("frozenlake", 1 << 26), ("pong", 65536)]:
+    for pol in ("device", "random"):
+        print(env, n, pol, run(["--env", env, "--num-envs", str(n), "--policy", pol]), flush=True)
+print("cartpole fast32", run(["--mode", "fast32"]), flush=True)
