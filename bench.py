@@ -29,6 +29,7 @@ from gym_amd import _lib as L  # noqa: E402
 from gym_amd.distributed import allreduce_stats, shard  # noqa: E402
 from gym_amd.engine import Context, DeviceBatch  # noqa: E402
 
+COLLECTIVE_DEVICE = "cuda"   # tensors handed to torch.distributed live here (cpu for the gloo rehearsal)
 HBM_PEAK_GBPS = 8000.0       # MI355X HBM3E peak
 FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X vector FP64 peak
 
@@ -75,7 +76,7 @@ def time_steps(batch, step_fn, steps, warmup, dist):
     wall = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / steps
     if dist is not None:
-        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        t = torch.tensor([wall], dtype=torch.float64, device=COLLECTIVE_DEVICE)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     return wall, kernel_ms
@@ -111,6 +112,9 @@ def main():
     ap.add_argument("--mode", default="exact", choices=["exact", "fast32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary Acrobot measurements")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl is RCCL on ROCm; gloo only to rehearse several ranks on one GPU")
+    ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses GPU local_rank %% device_count")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -121,9 +125,13 @@ def main():
         import torch.distributed as dist_mod
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.share_device:
+            local_rank %= torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group("nccl", rank=rank, world_size=world)
+        dist_mod.init_process_group(args.dist_backend, rank=rank, world_size=world)
         dist = dist_mod
+        global COLLECTIVE_DEVICE
+        COLLECTIVE_DEVICE = "cuda" if args.dist_backend == "nccl" else "cpu"
     else:
         torch.cuda.set_device(0)
     if world != args.gpus and rank == 0:
@@ -188,7 +196,7 @@ def main():
             pass
 
     # episode statistics: device reduction, then one RCCL all-reduce across ranks
-    ep = allreduce_stats(batch.stats(), dist, device="cuda")
+    ep = allreduce_stats(batch.stats(), dist, device=COLLECTIVE_DEVICE)
     out["episode_stats"] = {"episodes": ep["episodes"], "mean_length": ep["sum_length"] / max(ep["episodes"], 1),
                             "mean_return": ep["sum_return"] / max(ep["episodes"], 1),
                             "min_return": ep["min_return"], "max_return": ep["max_return"]}

@@ -99,6 +99,16 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s is missing: run `python -m gym_amd.build` (needs hipcc); there is no fallback path" % LIB_PATH)
+    # One HIP runtime per process: PyTorch wheels bundle their own libamdhip64, and a process
+    # that loads the system one first and torch's second ends up with two runtimes (torch then
+    # sees no GPU).  Importing torch first makes libgymx.so bind to the runtime torch loaded, so
+    # device pointers and streams can be shared between the two.  Hosts without torch (the C#
+    # binding) simply use the system runtime.
+    if not os.environ.get("GYMX_NO_TORCH"):
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)

@@ -161,3 +161,44 @@ class DeviceBatch:
         s = L.GxStats()
         L.check(L.load().gx_vec_stats(self._h, C.byref(s)))
         return s
+
+
+class _DevicePtr:
+    """Minimal __cuda_array_interface__ carrier so torch can wrap a library-owned row."""
+
+    def __init__(self, ptr, shape, typestr, owner):
+        self.__cuda_array_interface__ = {"shape": tuple(int(x) for x in shape), "typestr": typestr,
+                                         "data": (int(ptr), False), "version": 2}
+        self._owner = owner  # keeps the batch (and its device memory) alive
+
+
+_TYPESTR = {L.F32: "<f4", L.F64: "<f8", L.I32: "<i4", L.U8: "|u1"}
+
+
+def torch_views(batch):
+    """Zero-copy torch tensors over a batch's device rows (for agents that live on the GPU):
+    dict with state_real [n_real, stride], state_int [n_int, stride], reward [stride],
+    done [stride], obs (Pong: [num_envs, 100800]).  Valid until the batch is closed.  The
+    tensors carry no stream ordering: either launch the steps on torch's current stream (pass
+    its pointer as `stream`) or synchronise the context before reading."""
+    import torch
+
+    v = batch.view()
+    info = batch.info
+    out = {}
+
+    def wrap(ptr, shape, dt):
+        return torch.as_tensor(_DevicePtr(ptr, shape, _TYPESTR[dt], batch), device="cuda")
+
+    if info.n_real:
+        out["state_real"] = wrap(v.state_real, (info.n_real, v.stride), info.real_dtype)
+    out["state_int"] = wrap(v.state_int, (info.n_int, v.stride), L.I32)
+    out["reward"] = wrap(v.reward, (v.stride,), info.reward_dtype)
+    out["done"] = wrap(v.done, (v.stride,), L.U8)
+    if v.truncated:
+        out["truncated"] = wrap(v.truncated, (v.stride,), L.U8)
+    if batch.env_id == L.ENV_PONG:
+        out["obs"] = wrap(v.obs, (v.num_envs, info.obs_dim), L.U8)
+    elif not info.obs_is_state:
+        out["obs"] = wrap(v.obs, (info.obs_dim, v.stride), L.F32)
+    return out

@@ -1,0 +1,121 @@
+"""Parity at BASELINE.json's full sizes, through properties that do not need the oracle to step
+millions of envs: a K-step fused rollout equals K single steps; a batch split in two shards by
+global env index equals the unsplit batch; a window of the big batch equals an oracle batch keyed
+with the same global indices; statistics identities; frame invariants."""
+import numpy as np
+import pytest
+
+from gpu_common import L, bits, ctx
+from gym_amd.engine import DeviceBatch, torch_views
+
+pytestmark = pytest.mark.gpu
+
+FUSED = L.AUTORESET | L.RECORD_STATS
+N16 = 1 << 24
+
+
+def _window_matches_oracle(oracle, env_id, n_total, base, width, k, seed, flags, map_rows=None, o_rows=None):
+    """envs [base, base+width) of a big GPU batch stepped k times with the random policy
+    against an oracle batch of `width` envs keyed at the same global indices"""
+    g = DeviceBatch(ctx(), env_id, n_total, seed=seed, flags=flags, map_rows=map_rows)
+    o = oracle.OracleVec(env_id, width, seed=seed, flags=flags & ~L.RECORD_STATS, map_rows=o_rows, env_index_base=base)
+    g.reset(); o.reset()
+    for _ in range(k):
+        g.step_random(); o.step_random()
+    g.ctx.synchronize()  # the views are read on torch's stream, the steps ran on the context's
+    v = torch_views(g)
+    orr, oi = o.get_state()
+    if g.info.n_real:
+        gr = v["state_real"][:, base:base + width].cpu().numpy()
+        assert np.array_equal(bits(gr), bits(orr))
+    gi = v["state_int"][:, base:base + width].cpu().numpy()
+    assert np.array_equal(gi, oi)
+    return g, v
+
+
+def test_cartpole_16mi_window_rollout_sharding_stats(oracle):
+    k = 12
+    g, v = _window_matches_oracle(oracle, L.ENV_CARTPOLE, N16, base=N16 - 5000, width=4096, k=k, seed=5, flags=FUSED)
+    s = g.stats()
+    # CartPole pays 1 per step except the terminal one (Envs.CartPole.cs:72): return = length - 1
+    assert s.episodes > 0 and s.sum_return == s.sum_length - s.episodes
+    assert int(v["state_int"][0].max()) <= 500
+    # one fused K-step rollout == K single steps
+    g2 = DeviceBatch(ctx(), L.ENV_CARTPOLE, N16, seed=5, flags=FUSED)
+    g2.reset(); g2.rollout(k); g2.ctx.synchronize()
+    v2 = torch_views(g2)
+    import torch
+    assert torch.equal(v["state_real"].view(torch.int32), v2["state_real"].view(torch.int32))
+    assert torch.equal(v["state_int"], v2["state_int"])
+    s2 = g2.stats()
+    assert (s2.episodes, s2.sum_length, s2.sum_return, s2.sum_return_sq) == (s.episodes, s.sum_length, s.sum_return, s.sum_return_sq)
+    g2.close()
+    # two shards keyed by global env index == the unsplit batch
+    half = N16 // 2
+    parts = []
+    for r in range(2):
+        gs = DeviceBatch(ctx(), L.ENV_CARTPOLE, half, seed=5, flags=FUSED, env_index_base=r * half)
+        gs.reset()
+        for _ in range(k):
+            gs.step_random()
+        gs.ctx.synchronize()
+        vs = torch_views(gs)
+        assert torch.equal(vs["state_real"][:, :half].view(torch.int32), v["state_real"][:, r * half:(r + 1) * half].view(torch.int32))
+        parts.append(gs.stats())
+        gs.close()
+    assert parts[0].episodes + parts[1].episodes == s.episodes and parts[0].sum_return + parts[1].sum_return == s.sum_return
+
+
+def test_tabular_64mi_window(oracle):
+    n = 1 << 26
+    rows8 = ["SFFFFFFF", "FFFFFFFF", "FFFHFFFF", "FFFFFHFF", "FFFHFFFF", "FHHFFFHF", "FHFFHFHF", "FFFHFFFG"]
+    g, v = _window_matches_oracle(oracle, L.ENV_FROZENLAKE, n, base=n // 2 + 123, width=4096, k=40, seed=9,
+                                  flags=FUSED | L.SLIPPERY, map_rows="8x8", o_rows=rows8)
+    st = v["state_int"][0, :n]
+    assert int(st.min()) >= 0 and int(st.max()) < 64 and int(v["state_int"][1, :n].max()) <= 100
+    s = g.stats()
+    assert 0 <= s.sum_return <= s.episodes and s.min_return in (0.0, 1.0)
+    g.close()
+    g, v = _window_matches_oracle(oracle, L.ENV_TAXI, n, base=777, width=4096, k=10, seed=9, flags=FUSED)
+    assert int(v["state_int"][0, :n].max()) < 500
+    g.close()
+
+
+def test_pong_65536_frames(oracle):
+    import torch
+    n, k, base, width = 65536, 30, 60000, 64
+    g = DeviceBatch(ctx(), L.ENV_PONG, n, seed=2, flags=L.AUTORESET)
+    o = oracle.OracleVec(oracle.PONG, width, seed=2, flags=oracle.AUTORESET, env_index_base=base)
+    g.reset(); o.reset()
+    for _ in range(k):
+        g.step_random(); o.step_random()
+    g.ctx.synchronize()
+    v = torch_views(g)
+    frames = v["obs"]
+    assert np.array_equal(frames[base:base + width].cpu().numpy(), o.get_obs())
+    # every byte is 0 or 255 and the three channels are equal, for all 65 536 frames
+    f = frames.view(n, 210 * 160, 3)
+    assert bool(((f == 0) | (f == 255)).all())
+    assert bool((f[..., 0] == f[..., 1]).all()) and bool((f[..., 1] == f[..., 2]).all())
+    # 27 centre dashes (x in {79,80}) are lit in every frame unless the ball overlaps them: rows 8k..8k+3
+    dash = f.view(n, 210, 160, 3)[:, 0:4, 79:81, 0]
+    assert bool((dash == 255).all())
+    lit = (f[..., 0] == 255).sum(dim=1)
+    assert int(lit.min()) >= 27 * 8 + 2 * 30 - 8 and int(lit.max()) <= 27 * 8 + 60 + 4 + 2 * 2 * 15
+
+
+def test_acrobot_16mi_window_and_rk4_rollout(oracle):
+    g, v = _window_matches_oracle(oracle, L.ENV_ACROBOT, N16, base=1 << 23, width=2048, k=6, seed=4, flags=FUSED)
+    g.close()
+    # RK4/fp64 extension: K fused steps == K single steps, bit for bit
+    import torch
+    a = DeviceBatch(ctx(), L.ENV_ACROBOT, 1 << 22, seed=4, flags=FUSED | L.ACROBOT_RK4)
+    b = DeviceBatch(ctx(), L.ENV_ACROBOT, 1 << 22, seed=4, flags=FUSED | L.ACROBOT_RK4)
+    a.reset(); b.reset()
+    for _ in range(16):
+        a.step_random()
+    b.rollout(16)
+    a.ctx.synchronize()
+    va, vb = torch_views(a), torch_views(b)
+    assert torch.equal(va["state_real"].view(torch.int64), vb["state_real"].view(torch.int64))
+    assert torch.equal(va["obs"].view(torch.int32), vb["obs"].view(torch.int32))
