@@ -42,25 +42,38 @@ struct Acrobot64 {
     for (int i = 0; i < 4; i++) s[i] = fma(d.uniform(i), 0.2, -0.1);
   }
 
+  // 1/x to the last place or two: hardware estimate plus two Newton steps (this extension is
+  // held to 1e-9 relative, so a correctly rounded divide is not needed)
+  static __device__ __forceinline__ double recip(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+  }
+
+  // Derivative of (theta1, theta2, dtheta1, dtheta2).  Two sincos per evaluation: the book
+  // equations' cos(theta1 - pi/2) is sin(theta1) and cos(theta1 + theta2 - pi/2) is
+  // sin(theta1 + theta2) = s1 c2 + c1 s2.
   static __device__ __forceinline__ void dsdt(const double (&y)[4], double u, double (&dy)[4]) {
     const double g = 9.8;
     const double t1 = y[0], t2 = y[1], w1 = y[2], w2 = y[3];
-    double s2, c2, unused, c12, c1;
+    double s1, c1, s2, c2;
+    math::sincos_bounded(t1, s1, c1);
     math::sincos_bounded(t2, s2, c2);
-    math::sincos_bounded(t1 + t2 - M_PI / 2.0, unused, c12);
-    math::sincos_bounded(t1 - M_PI / 2.0, unused, c1);
+    const double s12 = fma(s1, c2, c1 * s2);
     const double d1 = c2 + 3.5;
     const double d2 = fma(0.5, c2, 1.25);
-    const double phi2 = (0.5 * g) * c12;
-    double phi1 = fma(1.5 * g, c1, phi2);
+    const double phi2 = (0.5 * g) * s12;
+    double phi1 = fma(1.5 * g, s1, phi2);
     phi1 = fma(-(w2 * s2), w1, phi1);
     phi1 = fma(-0.5 * (w2 * s2), w2, phi1);
-    const double r = d2 / d1;
+    const double inv_d1 = recip(d1);
+    const double r = d2 * inv_d1;
     double num = fma(r, phi1, u);
     num = fma(-0.5 * (w1 * s2), w1, num) - phi2;
     const double den = fma(-d2, r, 1.25);
-    const double a2 = num / den;
-    const double a1 = -fma(d2, a2, phi1) / d1;
+    const double a2 = num * recip(den);
+    const double a1 = -fma(d2, a2, phi1) * inv_d1;
     dy[0] = w1; dy[1] = w2; dy[2] = a1; dy[3] = a2;
   }
 
@@ -102,8 +115,9 @@ struct Acrobot64 {
     steps++;
     double sa, ca, sb, cb;
     math::sincos_bounded(y[0], sa, ca);
-    math::sincos_bounded(y[1] + y[0], sb, cb);
-    done = (-ca - cb > 1.0) || steps >= 500;
+    math::sincos_bounded(y[1], sb, cb);
+    // -cos(t1) - cos(t1 + t2), the second by the angle-addition formula
+    done = (-ca - fma(ca, cb, -(sa * sb)) > 1.0) || steps >= 500;
     reward = done ? 0.0f : -1.0f;
   }
 

@@ -24,13 +24,15 @@ __global__ void __launch_bounds__(256) k(Ptrs p, size_t nvec, int reverse) {
   }
 }
 
+static size_t g_lds = 0;  // dynamic LDS per workgroup: caps resident workgroups per CU (occupancy experiment)
+
 template <int NT_OUT>
 double run(Ptrs p, size_t nvec, int blocks, int alternate) {
   int iters = 40;
   hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
-  for (int i = 0; i < 4; i++) hipLaunchKernelGGL((k<NT_OUT>), dim3(blocks), dim3(256), 0, 0, p, nvec, alternate ? (i & 1) : 0);
+  for (int i = 0; i < 4; i++) hipLaunchKernelGGL((k<NT_OUT>), dim3(blocks), dim3(256), g_lds, 0, p, nvec, alternate ? (i & 1) : 0);
   CHECK(hipEventRecord(a));
-  for (int i = 0; i < iters; i++) hipLaunchKernelGGL((k<NT_OUT>), dim3(blocks), dim3(256), 0, 0, p, nvec, alternate ? (i & 1) : 0);
+  for (int i = 0; i < iters; i++) hipLaunchKernelGGL((k<NT_OUT>), dim3(blocks), dim3(256), g_lds, 0, p, nvec, alternate ? (i & 1) : 0);
   CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
   float ms; CHECK(hipEventElapsedTime(&ms, a, b));
   double bytes = (double)nvec * (6 * 32 + 16 + 16 + 4);
@@ -39,6 +41,12 @@ double run(Ptrs p, size_t nvec, int blocks, int alternate) {
 
 int main(int argc, char** argv) {
   int lg = argc > 1 ? atoi(argv[1]) : 24;
+  g_lds = argc > 2 ? (size_t)atoi(argv[2]) : 0;
+  if (g_lds > 65536) {
+    CHECK(hipFuncSetAttribute((const void*)k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_lds));
+    CHECK(hipFuncSetAttribute((const void*)k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_lds));
+  }
+  printf("dynamic LDS %zu B per workgroup -> at most %d workgroups (x4 waves) per CU\n", g_lds, g_lds ? (int)(163840 / g_lds) : 8);
   size_t nvec = ((size_t)1 << lg) / 4;
   Ptrs p;
   for (int s = 0; s < 6; s++) { CHECK(hipMalloc(&p.rw[s], nvec * 16)); CHECK(hipMemset(p.rw[s], 0, nvec * 16)); }
