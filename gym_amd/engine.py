@@ -202,3 +202,35 @@ def torch_views(batch):
     elif not info.obs_is_state:
         out["obs"] = wrap(v.obs, (info.obs_dim, v.stride), L.F32)
     return out
+
+
+class Comm:
+    """RCCL communicator for the episode-statistics all-reduce (hosts without torch.distributed).
+    Rank 0 creates the 128-byte id with Comm.unique_id() and hands it to the other ranks."""
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * 128)()
+        L.check(L.load().gx_comm_unique_id(C.cast(buf, C.c_void_p)))
+        return bytes(buf)
+
+    def __init__(self, ctx, unique_id, rank, world):
+        self._h = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        L.check(L.load().gx_comm_init(ctx._h, C.cast(buf, C.c_void_p), rank, world, C.byref(self._h)))
+
+    def allreduce_stats(self, batch):
+        s = L.GxStats()
+        L.check(L.load().gx_stats_allreduce(self._h, batch._h, C.byref(s)))
+        return s
+
+    def close(self):
+        if getattr(self, "_h", None):
+            L.load().gx_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -309,3 +309,17 @@ def test_acrobot_rk4_fp64_extension(oracle):
         gobs, oobs = g.get_obs(), o.get_obs()
         assert np.abs(gobs - oobs).max() <= 1e-6
         g.set_state(orr, oi)
+
+
+def test_rccl_stats_allreduce_single_rank(oracle):
+    """gx_comm_* / gx_stats_allreduce over RCCL with a world of one: the reduced record equals the local one"""
+    from gym_amd.engine import Comm
+    g, o = make_pair(oracle, L.ENV_CARTPOLE, 4096, seed=3, flags=L.AUTORESET | L.RECORD_STATS)
+    g.reset(); o.reset()
+    for _ in range(40):
+        g.step_random(); o.step_random()
+    comm = Comm(g.ctx, Comm.unique_id(), 0, 1)
+    s, local, so = comm.allreduce_stats(g), g.stats(), o.stats()
+    comm.close()
+    for f in ("episodes", "sum_return", "sum_length", "sum_return_sq", "min_return", "max_return"):
+        assert getattr(s, f) == getattr(local, f) == getattr(so, f), f
