@@ -44,9 +44,11 @@ B_ALG = {
     "pendulum": 12 + 12 + 4 + 4 + 4 + 8 + 8 + 8 + 1,       # 61: reward and ep_return are binary64
     "frozenlake": 4 + 4 + 4 + 4 + 4 + 4 + 4 + 4 + 1,       # 33
     "pong": 60 + 60 + 4 + 4 + 4 + 4 + 1 + 100800,          # 100937
+    "breakout": 72 + 72 + 4 + 4 + 4 + 4 + 1 + 100800,      # 100961
 }
 ENV_IDS = {"cartpole": L.ENV_CARTPOLE, "mountaincar": L.ENV_MOUNTAINCAR, "acrobot": L.ENV_ACROBOT,
-           "pendulum": L.ENV_PENDULUM, "frozenlake": L.ENV_FROZENLAKE, "pong": L.ENV_PONG}
+           "pendulum": L.ENV_PENDULUM, "frozenlake": L.ENV_FROZENLAKE, "pong": L.ENV_PONG, "breakout": L.ENV_BREAKOUT}
+FRAME_ENVS = ("pong", "breakout")
 # FP64 operations per env-step of the RK4 Acrobot (4 derivative evaluations of
 # ~32 flops, 52 for the RK4 combination, ~16 for wrap/clamp/termination),
 # transcendentals not counted
@@ -88,9 +90,9 @@ def cpu_baseline(env_name, target_seconds=12.0):
     from oracle import oracle as O
 
     eid = {"cartpole": O.CARTPOLE, "acrobot": O.ACROBOT, "mountaincar": O.MOUNTAINCAR, "pendulum": O.PENDULUM,
-           "frozenlake": O.FROZENLAKE, "pong": O.PONG}[env_name]
-    n = 1024 if env_name == "pong" else 1 << 16
-    secs, steps_done = O.bench_reference_shaped(eid, n, 8 if env_name == "pong" else 16)
+           "frozenlake": O.FROZENLAKE, "pong": O.PONG, "breakout": O.BREAKOUT}[env_name]
+    n = 1024 if env_name in FRAME_ENVS else 1 << 16
+    secs, steps_done = O.bench_reference_shaped(eid, n, 8 if env_name in FRAME_ENVS else 16)
     rate = steps_done / max(secs, 1e-9)
     k = max(8, int(target_seconds * rate / n))
     secs, steps_done = O.bench_reference_shaped(eid, n, k)
@@ -107,7 +109,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--env", default="cartpole", choices=sorted(ENV_IDS))
-    ap.add_argument("--num-envs", type=int, default=0, help="envs per GPU (default 16 Mi; Pong 65536)")
+    ap.add_argument("--num-envs", type=int, default=0, help="envs per GPU (default 16 Mi; Pong, Breakout 65536)")
     ap.add_argument("--policy", default="device", choices=["device", "random"])
     ap.add_argument("--mode", default="exact", choices=["exact", "fast32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -137,7 +139,7 @@ def main():
     if world != args.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
 
-    n = args.num_envs or (65536 if args.env == "pong" else 1 << 24)
+    n = args.num_envs or (65536 if args.env in FRAME_ENVS else 1 << 24)
     # a non-default torch stream: kernels are launched on it through the C ABI's stream
     # argument and the HIP events that time them are recorded on the same stream
     torch.cuda.set_stream(torch.cuda.Stream())
@@ -170,7 +172,8 @@ def main():
     out = {
         "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "u8" if args.env in FRAME_ENVS else ("i32" if args.env == "frozenlake" else "f32"),
+        "data": "synthetic",
         "config": {
             "workload": "%s VectorEnv.Step, %d envs/GPU, single-step kernel, auto-reset + RecordEpisodeStatistics fused, "
                         "%s, %s mode" % (args.env, n, "device-resident random actions (zero-copy path)"

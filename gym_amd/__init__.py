@@ -3,13 +3,13 @@ Gymnasium port (Env / VectorEnv / EnvRegistry / Spaces)."""
 from . import spaces
 from .env import (ActionWrapper, Env, EnvWrapper, ObservationWrapper, RecordEpisodeStatistics, RewardWrapper,
                   TimeLimit)
-from .envs import (Acrobot, CartPole, CliffWalking, DummyEnv, FrozenLake, MountainCar, MountainCarContinuous,
-                   Pendulum, Pong, Taxi)
+from .envs import (Acrobot, Breakout, CartPole, CliffWalking, DummyEnv, FrozenLake, MountainCar,
+                   MountainCarContinuous, Pendulum, Pong, Taxi)
 from .registry import EnvRegistry, RegisterAll
 from .spaces import Box, Discrete
 from .vector_env import VectorEnv
 
 __all__ = ["spaces", "Env", "EnvWrapper", "ObservationWrapper", "ActionWrapper", "RewardWrapper",
            "RecordEpisodeStatistics", "TimeLimit", "CartPole", "MountainCar", "MountainCarContinuous", "Pendulum",
-           "Acrobot", "FrozenLake", "Taxi", "CliffWalking", "Pong", "DummyEnv", "EnvRegistry", "RegisterAll", "Box",
-           "Discrete", "VectorEnv"]
+           "Acrobot", "FrozenLake", "Taxi", "CliffWalking", "Pong", "Breakout", "DummyEnv", "EnvRegistry", "RegisterAll",
+           "Box", "Discrete", "VectorEnv"]

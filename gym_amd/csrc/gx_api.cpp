@@ -59,7 +59,7 @@ struct gx_vec {
   std::string map;
   uint64_t n = 0, stride = 0, tick = 0;
   int envs_per_lane = 4;
-  bool is_classic = false, is_tabular = false, is_pong = false, is_acrobot64 = false;
+  bool is_classic = false, is_tabular = false, is_frame = false, is_acrobot64 = false;  // is_frame: Pong, Breakout
   bool ep_return_f64 = false;
   // device memory
   void* d_real = nullptr;
@@ -348,9 +348,24 @@ void fill_info(gx_vec* v) {
       in.n_real = 6; in.real_dtype = GX_F64; in.n_int = 3; in.obs_dim = 210 * 160 * 3; in.obs_dtype = GX_U8;
       in.action_n = 4; in.obs_is_state = 0;
       break;
+    case GX_ENV_BREAKOUT:                                                                         // Envs.Breakout.cs:44-48
+      in.n_real = 5; in.real_dtype = GX_F64; in.n_int = 8; in.obs_dim = 210 * 160 * 3; in.obs_dtype = GX_U8;
+      in.action_n = 4; in.obs_is_state = 0;
+      break;
   }
   in.state_bytes = v->n * ((uint64_t)in.n_real * dtype_size(in.real_dtype) + (uint64_t)in.n_int * 4);
   in.obs_bytes = v->n * (uint64_t)in.obs_dim * dtype_size(in.obs_dtype);
+}
+
+// the frame envs: game-state kernel, then the raster kernel over every env's frame
+hipError_t frame_step(const gx_vec* v, const StepArgs& a, int policy, hipStream_t stream) {
+  return v->desc.env_id == GX_ENV_PONG ? launch_pong_step(a, policy, v->grid, stream) : launch_breakout_step(a, policy, v->grid, stream);
+}
+hipError_t frame_reset(const gx_vec* v, const StepArgs& a, hipStream_t stream) {
+  return v->desc.env_id == GX_ENV_PONG ? launch_pong_reset(a, v->grid, stream) : launch_breakout_reset(a, v->grid, stream);
+}
+hipError_t frame_raster(const gx_vec* v, const StepArgs& a, hipStream_t stream) {
+  return v->desc.env_id == GX_ENV_PONG ? launch_pong_raster(a, v->d_frames, stream) : launch_breakout_raster(a, v->d_frames, stream);
 }
 
 StepArgs make_args(const gx_vec* v, const void* d_actions, int k_steps, uint64_t action_stride) {
@@ -396,8 +411,8 @@ int launch_step(gx_vec* v, const void* d_actions, int k_steps, uint64_t action_s
   else if (v->is_classic) e = launch_classic_step(v->desc.env_id, a, v->desc.mode, policy, fused, bounded, v->grid, stream);
   else if (v->is_tabular) e = launch_tabular_step(v->desc.env_id, a, policy, v->grid, v->table_lds_bytes, stream);
   else {
-    e = launch_pong_step(a, policy, v->grid, stream);
-    if (e == hipSuccess) e = launch_pong_raster(a, v->d_frames, stream);
+    e = frame_step(v, a, policy, stream);
+    if (e == hipSuccess) e = frame_raster(v, a, stream);
     v->frames_valid = true;
   }
   if (e != hipSuccess) return fail(GX_ERR_HIP, "step kernel launch failed: %s", hipGetErrorString(e));
@@ -416,7 +431,8 @@ int launch_sample(gx_vec* v, uint64_t tick, void* d_out, hipStream_t stream) {
   if (v->is_acrobot64) e = launch_acrobot64_sample(a, d_out, grid, stream);
   else if (v->is_classic) e = launch_classic_sample(v->desc.env_id, a, d_out, grid, stream);
   else if (v->is_tabular) e = launch_tabular_sample(v->desc.env_id, a, d_out, grid, stream);
-  else e = launch_pong_sample(a, d_out, grid, stream);
+  else if (v->desc.env_id == GX_ENV_PONG) e = launch_pong_sample(a, d_out, grid, stream);
+  else e = launch_breakout_sample(a, d_out, grid, stream);
   if (e != hipSuccess) return fail(GX_ERR_HIP, "sample kernel launch failed: %s", hipGetErrorString(e));
   return GX_OK;
 }
@@ -475,8 +491,8 @@ extern "C" int gx_vec_create(gx_ctx* ctx, const gx_desc* desc, gx_vec** out) {
   v->is_acrobot64 = env == GX_ENV_ACROBOT && (desc->flags & GX_ACROBOT_RK4);
   v->is_classic = env <= GX_ENV_ACROBOT;
   v->is_tabular = env == GX_ENV_FROZENLAKE || env == GX_ENV_TAXI || env == GX_ENV_CLIFFWALKING || env == GX_ENV_DUMMY;
-  v->is_pong = env == GX_ENV_PONG;
-  v->envs_per_lane = v->is_acrobot64 ? 2 : (v->is_pong ? 1 : 4);
+  v->is_frame = env == GX_ENV_PONG || env == GX_ENV_BREAKOUT;
+  v->envs_per_lane = v->is_acrobot64 ? 2 : (v->is_frame ? 1 : 4);
   v->stride = (v->n + 3) & ~3ull;  // rows stay 16-byte aligned for every element width
   v->ep_return_f64 = env == GX_ENV_MOUNTAINCAR_CONT || env == GX_ENV_PENDULUM;
   fill_info(v);
@@ -521,7 +537,7 @@ extern "C" int gx_vec_create(gx_ctx* ctx, const gx_desc* desc, gx_vec** out) {
   if (v->d_trunc) VEC_TRY(hipMemset(v->d_trunc, 0, v->stride));
   VEC_TRY(hipMemset(v->d_actions, 0, v->stride * 4));
   if (v->is_acrobot64) VEC_TRY(hipMalloc((void**)&v->d_obs, (size_t)6 * v->stride * 4));
-  if (v->is_pong) VEC_TRY(hipMalloc((void**)&v->d_frames, v->n * (size_t)in.obs_dim));
+  if (v->is_frame) VEC_TRY(hipMalloc((void**)&v->d_frames, v->n * (size_t)in.obs_dim));
 
   // launch geometry: enough workgroups to fill 256 CUs eight times over, each
   // grid-striding over lanes of `envs_per_lane` envs
@@ -549,11 +565,11 @@ extern "C" int gx_vec_create(gx_ctx* ctx, const gx_desc* desc, gx_vec** out) {
       VEC_TRY(hipMemset(v->d_ep_length, 0, v->stride * 4));
     }
   }
-  if (v->is_pong) {
-    // the Pong constructor calls Reset() (Envs.Pong.cs:47-52); tick stays 0
+  if (v->is_frame) {
+    // the Pong and Breakout constructors call Reset() (Envs.Pong.cs:47-52, Envs.Breakout.cs:54-60); tick stays 0
     StepArgs a = make_args(v, nullptr, 1, 0);
-    VEC_TRY(launch_pong_reset(a, v->grid, ctx->compute));
-    VEC_TRY(launch_pong_raster(a, v->d_frames, ctx->compute));
+    VEC_TRY(frame_reset(v, a, ctx->compute));
+    VEC_TRY(frame_raster(v, a, ctx->compute));
     v->frames_valid = true;
   } else if (v->is_tabular && env != GX_ENV_DUMMY && env != GX_ENV_TAXI) {
     // field initialisers: FrozenLake `_state` = 0, CliffWalking `_state` = 0 until Reset
@@ -597,8 +613,8 @@ extern "C" int gx_vec_reset(gx_vec* v) {
   else if (v->is_classic) e = launch_classic_reset(v->desc.env_id, a, v->grid, c->compute);
   else if (v->is_tabular) e = launch_tabular_reset(v->desc.env_id, a, v->grid, c->compute);
   else {
-    e = launch_pong_reset(a, v->grid, c->compute);
-    if (e == hipSuccess) e = launch_pong_raster(a, v->d_frames, c->compute);
+    e = frame_reset(v, a, c->compute);
+    if (e == hipSuccess) e = frame_raster(v, a, c->compute);
   }
   if (e != hipSuccess) return fail(GX_ERR_HIP, "reset kernel launch failed: %s", hipGetErrorString(e));
   v->tick += 1;
@@ -637,7 +653,7 @@ extern "C" int gx_vec_set_state(gx_vec* v, const void* host, size_t bytes) {
   HIP_TRY(hipStreamSynchronize(c->copy));
   v->state_dirty = true;
   StepArgs a = make_args(v, nullptr, 1, 0);
-  if (v->is_pong) HIP_TRY(launch_pong_raster(a, v->d_frames, c->compute));
+  if (v->is_frame) HIP_TRY(frame_raster(v, a, c->compute));
   if (v->is_acrobot64) HIP_TRY(launch_acrobot64_reset(a, 1, v->grid, c->compute));
   HIP_TRY(hipStreamSynchronize(c->compute));
   return GX_OK;
@@ -646,7 +662,7 @@ extern "C" int gx_vec_set_state(gx_vec* v, const void* host, size_t bytes) {
 // enqueue the device->host copy of the observation on `stream`
 static int copy_obs(gx_vec* v, void* host, hipStream_t stream) {
   const gx_info& in = v->info;
-  if (v->is_pong) {
+  if (v->is_frame) {
     HIP_TRY(hipMemcpyAsync(host, v->d_frames, in.obs_bytes, hipMemcpyDeviceToHost, stream));
     return GX_OK;
   }
@@ -753,7 +769,7 @@ extern "C" int gx_vec_device_view(gx_vec* v, gx_view* out) {
   out->stride = v->stride;
   out->state_real = v->d_real;
   out->state_int = v->d_int;
-  out->obs = v->is_pong ? (void*)v->d_frames : (v->is_acrobot64 ? (void*)v->d_obs : (v->is_tabular ? (void*)v->d_int : v->d_real));
+  out->obs = v->is_frame ? (void*)v->d_frames : (v->is_acrobot64 ? (void*)v->d_obs : (v->is_tabular ? (void*)v->d_int : v->d_real));
   out->reward = v->d_reward;
   out->done = v->d_done;
   out->truncated = v->d_trunc;

@@ -60,11 +60,6 @@ struct CartPole {
     const float theta_threshold_radians = 12 * (float)M_PI / 180;
     const float x_threshold = 2.4f;
 
-#if GX_DEBUG_COPY_ONLY
-    // bandwidth experiment: same rows moved, no dynamics
-    s[0] += 1.0f; s[1] += (float)action; steps++; done = s[2] > 1e30f; reward = s[3];
-    return;
-#endif
     float x = s[0], xDot = s[1], theta = s[2], thetaDot = s[3];
     float force = action == 1 ? force_mag : -force_mag;
     float sintheta, costheta;

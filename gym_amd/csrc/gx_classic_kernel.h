@@ -205,16 +205,6 @@ __global__ void __launch_bounds__(kBlock, (FUSED && BOUNDED) ? GX_FUSED_MIN_WAVE
           ep_len[j] = d ? 0 : ep_len[j];
         }
         pending |= d ? (1u << j) : 0u;
-#if GX_SERIALIZE_ENVS
-        // Make the next env's inputs look dependent on this env's result, so the compiler
-        // evaluates the envs of a lane one after the other instead of interleaving their
-        // long double-precision chains: a quarter of the live registers, more resident
-        // waves, and the waves hide the latency the interleave was hiding.
-        if (j + 1 < W) {
-#pragma unroll
-          for (int c = 0; c < NS; c++) asm volatile("" : "+v"(s[j + 1][c]) : "v"(s[j][NS - 1]));
-        }
-#endif
       }
       // Auto-reset, compacted: each lane resets one finished env per round, so a
       // wave runs the RNG max-per-lane times instead of once per env slot.

@@ -10,11 +10,11 @@
 #pragma clang fp contract(off)
 
 #include "gx_device.h"
+#include "gx_frame.h"
 #include "gx_launch.h"
 
 namespace gx {
 
-constexpr int kScreenW = 160, kScreenH = 210, kFrameBytes = kScreenW * kScreenH * 3;
 constexpr double kPaddleSpeed = 4.0, kBallSpeed = 3.0;
 constexpr int kPaddleH = 15, kPaddleW = 2, kBallSize = 2;
 
@@ -164,15 +164,6 @@ __global__ void __launch_bounds__(kBlock) pong_sample_kernel(StepArgs a, int32_t
     out[i] = philox_block(key, a.env_index_base + i, 2, 0).below(0, 4);
 }
 
-// 3x5 digit glyphs of Envs.Pong.cs:228-237, one byte per row, bit dx = column dx.
-__constant__ uint8_t kGlyphRows[10][5] = {
-    {7, 5, 5, 5, 7}, {2, 3, 2, 2, 7}, {7, 4, 7, 1, 7}, {7, 4, 7, 4, 7}, {5, 5, 7, 4, 4},
-    {7, 1, 7, 4, 7}, {7, 1, 7, 5, 7}, {7, 4, 4, 4, 4}, {7, 5, 7, 5, 7}, {7, 5, 7, 4, 7}};
-
-struct U3 {
-  uint32_t x, y, z;
-};
-
 // One workgroup per env.  A frame row is 160 pixels = 40 groups of four
 // pixels = 40 lanes x 12 bytes; the frame is 8400 such groups.
 __global__ void __launch_bounds__(kBlock) pong_raster_kernel(StepArgs a, uint8_t* __restrict__ frames) {
@@ -185,24 +176,10 @@ __global__ void __launch_bounds__(kBlock) pong_raster_kernel(StepArgs a, uint8_t
   if (threadIdx.x < 25) digit_rows[threadIdx.x / 5][threadIdx.x % 5] = 0;
   __syncthreads();
   if (threadIdx.x < 10) {
-    // Envs.Pong.cs:211-251: decimal string, digit i at startX + 8 i, rows y0..y0+4
+    // Envs.Pong.cs:211-251: decimal string centred on centerX, digit i at startX + 8 i, rows 20..24
     const int side = threadIdx.x / 5, row = threadIdx.x % 5;
     const int score = a.state_int[(uint64_t)side * a.stride + env];
-    const int centerX = side ? 3 * kScreenW / 4 : kScreenW / 4;
-    uint32_t mag = score < 0 ? 0u - (uint32_t)score : (uint32_t)score;
-    int ndig = 1;
-    for (uint32_t t = mag; t >= 10; t /= 10) ndig++;
-    const int len = ndig + (score < 0 ? 1 : 0);  // a '-' occupies a cell and draws nothing
-    const int startX = centerX - (len * 6) / 2;
-    for (int i = len - 1; i >= len - ndig; i--) {
-      const uint32_t g = kGlyphRows[mag % 10][row];
-      mag /= 10;
-#pragma unroll
-      for (int dx = 0; dx < 3; dx++) {
-        const int px = startX + 8 * i + dx;
-        if (((g >> dx) & 1u) && px >= 0 && px < kScreenW) atomicOr(&digit_rows[row][px >> 5], 1u << (px & 31));
-      }
-    }
+    score_row_mask(digit_rows[row], score, row, side ? 3 * kScreenW / 4 : kScreenW / 4, 8, true);
   }
   __syncthreads();
 
@@ -219,12 +196,10 @@ __global__ void __launch_bounds__(kBlock) pong_raster_kernel(StepArgs a, uint8_t
     }
     if (y >= 20 && y < 25) nib |= (digit_rows[y - 20][g >> 3] >> (4 * (g & 7))) & 0xFu;
     // four pixels -> twelve bytes, three bytes of 0xFF per set pixel
-    const uint32_t p0 = 0u - (nib & 1u), p1 = 0u - ((nib >> 1) & 1u), p2 = 0u - ((nib >> 2) & 1u), p3 = 0u - ((nib >> 3) & 1u);
-    U3 v;
-    v.x = (p0 & 0x00FFFFFFu) | (p1 & 0xFF000000u);
-    v.y = (p1 & 0x0000FFFFu) | (p2 & 0xFFFF0000u);
-    v.z = (p2 & 0x000000FFu) | (p3 & 0xFFFFFF00u);
-    *reinterpret_cast<U3*>(frame + (uint64_t)c * 12) = v;
+    const uint32_t white = 0x00FFFFFFu;
+    *reinterpret_cast<U3*>(frame + (uint64_t)c * 12) =
+        pack_rgb4((0u - (nib & 1u)) & white, (0u - ((nib >> 1) & 1u)) & white, (0u - ((nib >> 2) & 1u)) & white,
+                  (0u - ((nib >> 3) & 1u)) & white);
   }
 }
 

@@ -110,7 +110,7 @@ class DeviceBatch:
         self.set_state_raw(np.concatenate([r, i]))
 
     def obs_shape(self):
-        if self.env_id == L.ENV_PONG:
+        if self.info.obs_dtype == L.U8:  # Pong, Breakout frames
             return (self.n, self.info.obs_dim)
         if self.info.obs_dtype == L.I32:
             return (self.n,)
@@ -178,7 +178,7 @@ _TYPESTR = {L.F32: "<f4", L.F64: "<f8", L.I32: "<i4", L.U8: "|u1"}
 def torch_views(batch):
     """Zero-copy torch tensors over a batch's device rows (for agents that live on the GPU):
     dict with state_real [n_real, stride], state_int [n_int, stride], reward [stride],
-    done [stride], obs (Pong: [num_envs, 100800]).  Valid until the batch is closed.  The
+    done [stride], obs (Pong, Breakout: [num_envs, 100800]).  Valid until the batch is closed.  The
     tensors carry no stream ordering: either launch the steps on torch's current stream (pass
     its pointer as `stream`) or synchronise the context before reading."""
     import torch
@@ -197,7 +197,7 @@ def torch_views(batch):
     out["done"] = wrap(v.done, (v.stride,), L.U8)
     if v.truncated:
         out["truncated"] = wrap(v.truncated, (v.stride,), L.U8)
-    if batch.env_id == L.ENV_PONG:
+    if info.obs_dtype == L.U8:
         out["obs"] = wrap(v.obs, (v.num_envs, info.obs_dim), L.U8)
     elif not info.obs_is_state:
         out["obs"] = wrap(v.obs, (info.obs_dim, v.stride), L.F32)

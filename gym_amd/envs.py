@@ -220,6 +220,38 @@ class Pong(DeviceEnv):
                 "ball_x": float(reals[0, index]), "ball_y": float(reals[1, index])}
 
 
+class Breakout(DeviceEnv):
+    """Envs.Breakout.cs:12-360: Env<byte[], int>; the observation is the 210x160x3 frame"""
+    ENV_ID, ID = L.ENV_BREAKOUT, "Breakout-v4"
+    FRAME = 210 * 160 * 3
+
+    def __init__(self, **kw):
+        super().__init__(**kw)
+        self.ActionSpace = Discrete(4)  # 0 NOOP, 1 FIRE, 2 RIGHT, 3 LEFT
+        self.ObservationSpace = Box(np.zeros(self.FRAME, np.float32), np.full(self.FRAME, 255.0, np.float32))
+
+    @property
+    def Spec(self):
+        return {"id": "Breakout-v4", "max_episode_steps": 10000}  # Envs.Breakout.cs:50
+
+    @property
+    def Metadata(self):
+        return {"render_modes": ["human", "rgb_array"]}
+
+    @property
+    def RewardRange(self):
+        return (0, 7)
+
+    def _state_of(self, obs, index=0):
+        return np.array(obs[index], np.uint8)
+
+    def _info(self, batch, index=0):
+        reals, ints = batch.get_state()  # Envs.Breakout.cs:203-210
+        words = ints[3:7, index].astype(np.int64) & 0xFFFFFFFF
+        return {"score": int(ints[0, index]), "lives": int(ints[1, index]), "ball_x": float(reals[0, index]),
+                "ball_y": float(reals[1, index]), "bricks_remaining": sum(bin(int(w)).count("1") for w in words)}
+
+
 class DummyEnv(_IntStateEnv):
     """DummyEnv.cs:10-38"""
     ENV_ID, ID = L.ENV_DUMMY, "Dummy"

@@ -56,7 +56,8 @@ typedef enum gx_env_id {
   GX_ENV_CLIFFWALKING = 7,     /* "CliffWalking-v0"          Envs.CliffWalking.cs */
   GX_ENV_PONG = 8,             /* "Pong-v4"                  Envs.Pong.cs */
   GX_ENV_DUMMY = 9,            /* DummyEnv.cs */
-  GX_ENV_COUNT = 10
+  GX_ENV_BREAKOUT = 10,        /* "Breakout-v4"              Envs.Breakout.cs */
+  GX_ENV_COUNT = 11
 } gx_env_id;
 
 /* Numeric mode of the continuous-control kernels. */
@@ -115,7 +116,7 @@ typedef struct gx_info {
   int32_t real_dtype;      /* GX_F32 or GX_F64 */
   int32_t n_int;           /* int32 state components, the last is the step counter */
   int32_t obs_dim;         /* elements per env in the observation */
-  int32_t obs_dtype;       /* GX_F32 (classic control), GX_I32 (tabular), GX_U8 (Pong) */
+  int32_t obs_dtype;       /* GX_F32 (classic control), GX_I32 (tabular), GX_U8 (Pong, Breakout) */
   int32_t action_dtype;    /* GX_I32 (Discrete) or GX_F32 (Box of dimension 1) */
   int32_t action_n;        /* Discrete.N, or 0 for Box */
   float action_low, action_high; /* Box bounds when action_dtype == GX_F32 */
@@ -132,7 +133,7 @@ typedef struct gx_view {
   void* state_real;   /* [n_real][stride] float or double */
   int32_t* state_int; /* [n_int][stride] */
   void* obs;          /* classic: == state_real (or float [obs_dim][stride] when it is derived);
-                         tabular: == state_int; Pong: uint8 [num_envs][100800] */
+                         tabular: == state_int; Pong, Breakout: uint8 [num_envs][100800] */
   void* reward;       /* [num_envs] float or double (gx_info.reward_dtype) */
   uint8_t* done;      /* [num_envs] */
   uint8_t* truncated; /* [num_envs], NULL unless time_limit > 0 */
@@ -172,11 +173,19 @@ int gx_vec_info(const gx_vec* vec, gx_info* out);
 int gx_vec_reset(gx_vec* vec);
 
 /* The reference keeps state private and has no setter; these exist for the
- * replay harness and double as checkpoint/resume.  Synchronous. */
+ * replay harness and double as checkpoint/resume.  Synchronous.
+ * Components of the SoA image (reals | ints), named after the reference's fields:
+ *   CartPole   x, xDot, theta, thetaDot | steps          MountainCar(+Cont)  position, velocity | steps
+ *   Pendulum   cos, sin, thetaDot | steps                Acrobot  cos1, sin1, cos2, sin2, thetaDot1, thetaDot2 | steps
+ *   Acrobot+RK4 (f64) theta1, theta2, dtheta1, dtheta2 | steps
+ *   tabular, Dummy   - | state, steps
+ *   Pong (f64)     ballX, ballY, ballVelX, ballVelY, leftPaddleY, rightPaddleY | leftScore, rightScore, steps
+ *   Breakout (f64) ballX, ballY, ballVelX, ballVelY, paddleX | score, lives, ballStuck,
+ *                  bricks[0..3] (bit row*18+col of word (row*18+col)/32 set = brick present), steps */
 int gx_vec_get_state(gx_vec* vec, void* host_soa, size_t bytes);
 int gx_vec_set_state(gx_vec* vec, const void* host_soa, size_t bytes);
 /* Observation of every env as Reset()/Step() would return it: classic control
- * float[obs_dim][num_envs]; tabular int32[num_envs]; Pong uint8[num_envs][100800].
+ * float[obs_dim][num_envs]; tabular int32[num_envs]; Pong and Breakout uint8[num_envs][100800].
  * Synchronous. */
 int gx_vec_get_obs(gx_vec* vec, void* host_obs, size_t bytes);
 

@@ -887,6 +887,187 @@ static void pong_import(env_obj* e, const void* reals, const int32_t* ints) {
 }
 static const env_vtbl pong_vt = {pong_reset, pong_step, pong_export, pong_import, sizeof(pong_t)};
 
+/* ---------------------------------------------------------------- Breakout */
+#define BK_PADDLE_SPEED 5.0
+#define BK_BALL_SPEED 3.0
+#define BK_PADDLE_HEIGHT 4
+#define BK_PADDLE_WIDTH 16
+#define BK_BALL_SIZE 2
+#define BK_BRICK_WIDTH 8
+#define BK_BRICK_HEIGHT 6
+#define BK_BRICK_ROWS 6
+#define BK_BRICK_COLS 18
+#define BK_BRICK_START_Y 60
+
+typedef struct {
+  env_obj base;
+  double ballX, ballY, ballVelX, ballVelY, paddleX;
+  int32_t score, lives, ballStuck;
+  uint8_t bricks[BK_BRICK_ROWS][BK_BRICK_COLS];
+  int32_t steps;
+} breakout_t;
+
+/* Envs.Breakout.cs:62-87 (no random draw) */
+static void breakout_reset(env_obj* e, const rng_ctx* r) {
+  (void)r;
+  breakout_t* c = (breakout_t*)e;
+  for (int row = 0; row < BK_BRICK_ROWS; row++)
+    for (int col = 0; col < BK_BRICK_COLS; col++) c->bricks[row][col] = 1;
+  c->paddleX = SCREEN_WIDTH / 2.0 - BK_PADDLE_WIDTH / 2.0;
+  c->ballX = SCREEN_WIDTH / 2.0;
+  c->ballY = SCREEN_HEIGHT - 30;
+  c->ballVelX = 0;
+  c->ballVelY = 0;
+  c->ballStuck = 1;
+  c->score = 0;
+  c->lives = 5;
+  c->steps = 0;
+}
+
+/* Envs.Breakout.cs:89-213 (game state only; the frame is drawn by gxo_breakout_render) */
+static int breakout_step(env_obj* e, const void* action, const rng_ctx* r, double* reward, int* done) {
+  breakout_t* c = (breakout_t*)e;
+  int a = *(const int32_t*)action;
+  c->steps++;
+  double rew = 0.0;
+  switch (a) {
+    case 1:
+      if (c->ballStuck) {
+        c->ballStuck = 0;
+        /* the only random draw of the env: stream 1 (inside Step), draw 0 */
+        c->ballVelX = (gxo_rng_uniform(r->seed, r->env_index, r->tick, 1, 0) - 0.5) * 2.0 * BK_BALL_SPEED;
+        c->ballVelY = -BK_BALL_SPEED;
+      }
+      break;
+    case 2:
+      c->paddleX = dmin(SCREEN_WIDTH - BK_PADDLE_WIDTH, c->paddleX + BK_PADDLE_SPEED);
+      if (c->ballStuck) c->ballX = c->paddleX + BK_PADDLE_WIDTH / 2.0;
+      break;
+    case 3:
+      c->paddleX = dmax(0, c->paddleX - BK_PADDLE_SPEED);
+      if (c->ballStuck) c->ballX = c->paddleX + BK_PADDLE_WIDTH / 2.0;
+      break;
+    default: break;
+  }
+  if (!c->ballStuck) {
+    c->ballX += c->ballVelX;
+    c->ballY += c->ballVelY;
+    if (c->ballX <= 0 || c->ballX >= SCREEN_WIDTH - BK_BALL_SIZE) {
+      c->ballVelX = -c->ballVelX;
+      c->ballX = dmax(0, dmin(SCREEN_WIDTH - BK_BALL_SIZE, c->ballX));
+    }
+    if (c->ballY <= 0) {
+      c->ballVelY = -c->ballVelY;
+      c->ballY = 0;
+    }
+    if (c->ballY + BK_BALL_SIZE >= SCREEN_HEIGHT - 20 && c->ballY + BK_BALL_SIZE <= SCREEN_HEIGHT - 16 &&
+        c->ballX + BK_BALL_SIZE >= c->paddleX && c->ballX <= c->paddleX + BK_PADDLE_WIDTH) {
+      c->ballVelY = -fabs(c->ballVelY);
+      double relativeIntersectX = (c->ballX + BK_BALL_SIZE / 2.0) - (c->paddleX + BK_PADDLE_WIDTH / 2.0);
+      double normalizedIntersectX = relativeIntersectX / (BK_PADDLE_WIDTH / 2.0);
+      c->ballVelX = normalizedIntersectX * BK_BALL_SPEED * 0.75;
+    }
+    /* (int) truncates toward zero: a ball with 54 < y < 60 lands in brick row 0 */
+    int brickRow = (int)((c->ballY - BK_BRICK_START_Y) / BK_BRICK_HEIGHT);
+    int brickCol = (int)(c->ballX / BK_BRICK_WIDTH);
+    if (brickRow >= 0 && brickRow < BK_BRICK_ROWS && brickCol >= 0 && brickCol < BK_BRICK_COLS &&
+        c->bricks[brickRow][brickCol]) {
+      c->bricks[brickRow][brickCol] = 0;
+      c->ballVelY = -c->ballVelY;
+      rew = (BK_BRICK_ROWS - brickRow) + 1;
+      c->score += (int)rew;
+    }
+    if (c->ballY > SCREEN_HEIGHT) {
+      c->lives--;
+      if (c->lives > 0) {
+        c->ballX = c->paddleX + BK_PADDLE_WIDTH / 2.0;
+        c->ballY = SCREEN_HEIGHT - 30;
+        c->ballVelX = 0;
+        c->ballVelY = 0;
+        c->ballStuck = 1;
+      }
+    }
+  }
+  int allBricksGone = 1;
+  for (int row = 0; row < BK_BRICK_ROWS && allBricksGone; row++)
+    for (int col = 0; col < BK_BRICK_COLS && allBricksGone; col++)
+      if (c->bricks[row][col]) allBricksGone = 0;
+  if (allBricksGone) rew += 100;
+  *done = c->lives <= 0 || allBricksGone || c->steps >= 10000;
+  *reward = rew;
+  return 0;
+}
+
+/* Envs.Breakout.cs:287-304 */
+static void draw_rect_rgb(uint8_t* screen, int x, int y, int width, int height, uint8_t r, uint8_t g, uint8_t b) {
+  for (int dy = 0; dy < height; dy++)
+    for (int dx = 0; dx < width; dx++) {
+      int px = x + dx, py = y + dy;
+      if (px >= 0 && px < SCREEN_WIDTH && py >= 0 && py < SCREEN_HEIGHT) {
+        int index = (py * SCREEN_WIDTH + px) * CHANNELS;
+        screen[index] = r;
+        screen[index + 1] = g;
+        screen[index + 2] = b;
+      }
+    }
+}
+
+/* Envs.Breakout.cs:229-285, 306-344.  `bricks` holds bit row*18+col of word
+ * (row*18+col)/32; the glyph table (:321-330) equals Pong's (Envs.Pong.cs:228-237). */
+void gxo_breakout_render(double ball_x, double ball_y, double paddle_x, int ball_stuck, int score, int lives,
+                         const uint32_t bricks[4], uint8_t* screen) {
+  static const uint8_t rgb[BK_BRICK_ROWS][3] = {{255, 0, 0}, {255, 165, 0}, {255, 255, 0},
+                                                {0, 255, 0}, {0, 0, 255},   {128, 0, 128}};
+  memset(screen, 0, GXO_PONG_FRAME_BYTES);
+  for (int row = 0; row < BK_BRICK_ROWS; row++)
+    for (int col = 0; col < BK_BRICK_COLS; col++) {
+      int bit = row * BK_BRICK_COLS + col;
+      if ((bricks[bit >> 5] >> (bit & 31)) & 1u)
+        draw_rect_rgb(screen, col * BK_BRICK_WIDTH, BK_BRICK_START_Y + row * BK_BRICK_HEIGHT, BK_BRICK_WIDTH - 1,
+                      BK_BRICK_HEIGHT - 1, rgb[row][0], rgb[row][1], rgb[row][2]);
+    }
+  draw_rectangle(screen, (int)paddle_x, SCREEN_HEIGHT - 20, BK_PADDLE_WIDTH, BK_PADDLE_HEIGHT);
+  if (!ball_stuck)
+    draw_rectangle(screen, (int)ball_x, (int)ball_y, BK_BALL_SIZE, BK_BALL_SIZE);
+  else
+    draw_rectangle(screen, (int)(paddle_x + BK_PADDLE_WIDTH / 2.0 - BK_BALL_SIZE / 2.0), SCREEN_HEIGHT - 30,
+                   BK_BALL_SIZE, BK_BALL_SIZE);
+  char str[16];
+  int len = snprintf(str, sizeof str, "%d", score);
+  for (int i = 0; i < len; i++) draw_digit(screen, str[i], 10 + i * 6, 10);
+  for (int i = 0; i < lives; i++) draw_rectangle(screen, 10 + i * 8, 25, 6, 3);
+}
+
+/* state image: reals ballX, ballY, ballVelX, ballVelY, paddleX; ints score, lives,
+ * ballStuck, four words of brick bits, steps */
+static void breakout_export(const env_obj* e, void* reals, int32_t* ints) {
+  const breakout_t* c = (const breakout_t*)e;
+  double* d = (double*)reals;
+  d[0] = c->ballX; d[1] = c->ballY; d[2] = c->ballVelX; d[3] = c->ballVelY; d[4] = c->paddleX;
+  ints[0] = c->score; ints[1] = c->lives; ints[2] = c->ballStuck;
+  uint32_t w[4] = {0, 0, 0, 0};
+  for (int row = 0; row < BK_BRICK_ROWS; row++)
+    for (int col = 0; col < BK_BRICK_COLS; col++) {
+      int bit = row * BK_BRICK_COLS + col;
+      if (c->bricks[row][col]) w[bit >> 5] |= 1u << (bit & 31);
+    }
+  for (int k = 0; k < 4; k++) ints[3 + k] = (int32_t)w[k];
+  ints[7] = c->steps;
+}
+static void breakout_import(env_obj* e, const void* reals, const int32_t* ints) {
+  breakout_t* c = (breakout_t*)e;
+  const double* d = (const double*)reals;
+  c->ballX = d[0]; c->ballY = d[1]; c->ballVelX = d[2]; c->ballVelY = d[3]; c->paddleX = d[4];
+  c->score = ints[0]; c->lives = ints[1]; c->ballStuck = ints[2] != 0;
+  for (int row = 0; row < BK_BRICK_ROWS; row++)
+    for (int col = 0; col < BK_BRICK_COLS; col++) {
+      int bit = row * BK_BRICK_COLS + col;
+      c->bricks[row][col] = (uint8_t)(((uint32_t)ints[3 + (bit >> 5)] >> (bit & 31)) & 1u);
+    }
+  c->steps = ints[7];
+}
+static const env_vtbl breakout_vt = {breakout_reset, breakout_step, breakout_export, breakout_import, sizeof(breakout_t)};
+
 /* ======================================================================
  * Wrappers and the batched driver.
  * ====================================================================== */
@@ -982,6 +1163,7 @@ gxo_vec* gxo_vec_create(int env_id, uint64_t num_envs, uint64_t seed, uint32_t f
     case GXO_TAXI: vt = &taxi_vt; v->n_real = 0; v->n_int = 2; v->obs_dim = 1; break;
     case GXO_DUMMY: vt = &dummy_vt; v->n_real = 0; v->n_int = 2; v->obs_dim = 1; break;
     case GXO_PONG: vt = &pong_vt; v->n_real = 6; v->real_is_f64 = 1; v->n_int = 3; v->obs_dim = GXO_PONG_FRAME_BYTES; break;
+    case GXO_BREAKOUT: vt = &breakout_vt; v->n_real = 5; v->real_is_f64 = 1; v->n_int = 8; v->obs_dim = GXO_PONG_FRAME_BYTES; break;
   }
   if (env_id == GXO_FROZENLAKE || env_id == GXO_CLIFFWALKING) {
     grid_desc* g = (grid_desc*)calloc(1, sizeof *g);
@@ -1014,12 +1196,13 @@ gxo_vec* gxo_vec_create(int env_id, uint64_t num_envs, uint64_t seed, uint32_t f
   v->cur_reward = (double*)calloc(num_envs ? num_envs : 1, sizeof(double));
   v->cur_length = (int32_t*)calloc(num_envs ? num_envs : 1, sizeof(int32_t));
   v->episodes = (episode_list*)calloc(num_envs ? num_envs : 1, sizeof(episode_list));
-  if (env_id == GXO_PONG) {
-    /* The Pong constructor calls Reset() (Envs.Pong.cs:47-52).  That draw is
-     * unobservable once the batch is reset, so construction leaves tick at 0. */
+  if (env_id == GXO_PONG || env_id == GXO_BREAKOUT) {
+    /* The Pong and Breakout constructors call Reset() (Envs.Pong.cs:47-52,
+     * Envs.Breakout.cs:54-60).  Pong's draw is unobservable once the batch is
+     * reset, so construction leaves tick at 0. */
     for (uint64_t i = 0; i < num_envs; i++) {
       rng_ctx r = {seed, env_index_base + i, 0};
-      pong_reset(v->envs[i], &r);
+      vt->reset(v->envs[i], &r);
     }
   }
   return v;
@@ -1092,7 +1275,7 @@ static int vec_step_impl(gxo_vec* v, const void* actions, int random_policy, voi
           af = gxo_box_sample(u, -2.0f, 2.0f);
           break;
         default: {
-          static const int nact[GXO_NUM_ENVS] = {2, 3, 0, 0, 3, 4, 6, 4, 4, 3};
+          static const int nact[GXO_NUM_ENVS] = {2, 3, 0, 0, 3, 4, 6, 4, 4, 3, 4};
           ai = gxo_rng_below(r.seed, r.env_index, r.tick, 2, 0, nact[v->env_id]);
         }
       }
@@ -1146,7 +1329,7 @@ void gxo_vec_get_state(const gxo_vec* v, void* buf) {
   char* reals = (char*)buf;
   int32_t* ints = (int32_t*)(reals + (size_t)v->n * v->n_real * rsz);
   double tmp[8];
-  int32_t itmp[4];
+  int32_t itmp[8];
   for (uint64_t i = 0; i < v->n; i++) {
     v->envs[i]->vt->export_state(v->envs[i], tmp, itmp);
     for (int k = 0; k < v->n_real; k++)
@@ -1160,7 +1343,7 @@ void gxo_vec_set_state(gxo_vec* v, const void* buf) {
   const char* reals = (const char*)buf;
   const int32_t* ints = (const int32_t*)(reals + (size_t)v->n * v->n_real * rsz);
   double tmp[8];
-  int32_t itmp[4];
+  int32_t itmp[8];
   for (uint64_t i = 0; i < v->n; i++) {
     for (int k = 0; k < v->n_real; k++)
       memcpy((char*)tmp + (size_t)k * rsz, reals + ((size_t)k * v->n + i) * rsz, rsz);
@@ -1173,12 +1356,15 @@ void gxo_vec_set_state(gxo_vec* v, const void* buf) {
 
 void gxo_vec_get_obs(const gxo_vec* v, void* buf) {
   double tmp[8];
-  int32_t itmp[4];
+  int32_t itmp[8];
   for (uint64_t i = 0; i < v->n; i++) {
     v->envs[i]->vt->export_state(v->envs[i], tmp, itmp);
     if (v->env_id == GXO_PONG) {
       gxo_pong_render(tmp[0], tmp[1], tmp[4], tmp[5], itmp[0], itmp[1],
                       (uint8_t*)buf + (size_t)i * GXO_PONG_FRAME_BYTES);
+    } else if (v->env_id == GXO_BREAKOUT) {
+      gxo_breakout_render(tmp[0], tmp[1], tmp[4], itmp[2], itmp[0], itmp[1], (const uint32_t*)&itmp[3],
+                          (uint8_t*)buf + (size_t)i * GXO_PONG_FRAME_BYTES);
     } else if (v->env_id == GXO_ACROBOT && v->real_is_f64) {
       float* o = (float*)buf;
       o[0 * v->n + i] = (float)cos(tmp[0]);
@@ -1237,7 +1423,7 @@ double gxo_bench_reference_shaped(int env_id, uint64_t num_envs, int steps, uint
   if (!v) return -1.0;
   gxo_vec_reset(v);
   void* actions = malloc(num_envs * 4);
-  static const int nact[GXO_NUM_ENVS] = {2, 3, 0, 0, 3, 4, 6, 4, 4, 3};
+  static const int nact[GXO_NUM_ENVS] = {2, 3, 0, 0, 3, 4, 6, 4, 4, 3, 4};
   for (uint64_t i = 0; i < num_envs; i++) {
     if (v->action_is_float) {
       float lim = env_id == GXO_PENDULUM ? 2.0f : 1.0f;
@@ -1247,7 +1433,7 @@ double gxo_bench_reference_shaped(int env_id, uint64_t num_envs, int steps, uint
     }
   }
   /* every Pong object owns its 210x160x3 `_screen` (Envs.Pong.cs:49) */
-  uint8_t* screens = env_id == GXO_PONG ? (uint8_t*)malloc(num_envs * (size_t)GXO_PONG_FRAME_BYTES) : NULL;
+  uint8_t* screens = (env_id == GXO_PONG || env_id == GXO_BREAKOUT) ? (uint8_t*)malloc(num_envs * (size_t)GXO_PONG_FRAME_BYTES) : NULL;
   double acc = 0.0;
   struct timespec t0, t1;
   clock_gettime(CLOCK_MONOTONIC, &t0);
@@ -1257,7 +1443,7 @@ double gxo_bench_reference_shaped(int env_id, uint64_t num_envs, int steps, uint
       rng_ctx r = {seed, i, v->tick};
       env_obj* e = v->envs[i];
       const void* ap = (const char*)actions + i * 4;
-      int32_t ints[4];
+      int32_t ints[8];
       e->vt->step(e, ap, &r, &results[i].reward, &results[i].done);
       e->vt->export_state(e, results[i].state, ints);
       results[i].info = NULL;
@@ -1265,7 +1451,11 @@ double gxo_bench_reference_shaped(int env_id, uint64_t num_envs, int steps, uint
       if (screens) { /* Envs.Pong.cs:146 RenderScreen() on every step */
         const double* st = results[i].state;
         e->vt->export_state(e, results[i].state, ints);
-        gxo_pong_render(st[0], st[1], st[4], st[5], ints[0], ints[1], screens + i * (size_t)GXO_PONG_FRAME_BYTES);
+        if (env_id == GXO_PONG)
+          gxo_pong_render(st[0], st[1], st[4], st[5], ints[0], ints[1], screens + i * (size_t)GXO_PONG_FRAME_BYTES);
+        else
+          gxo_breakout_render(st[0], st[1], st[4], ints[2], ints[0], ints[1], (const uint32_t*)&ints[3],
+                              screens + i * (size_t)GXO_PONG_FRAME_BYTES);
         acc += screens[i * (size_t)GXO_PONG_FRAME_BYTES + 60];
       }
     }

@@ -41,7 +41,8 @@ enum {
   GXO_CLIFFWALKING = 7,  /* Envs.CliffWalking.cs */
   GXO_PONG = 8,          /* Envs.Pong.cs */
   GXO_DUMMY = 9,         /* DummyEnv.cs */
-  GXO_NUM_ENVS = 10
+  GXO_BREAKOUT = 10,     /* Envs.Breakout.cs */
+  GXO_NUM_ENVS = 11
 };
 
 /* Wrapper / engine flags. */
@@ -111,6 +112,10 @@ void gxo_vec_episode_get(const gxo_vec* v, uint64_t env, size_t k, double* ret, 
 /* Pong raster alone (Envs.Pong.cs:167-251) for frame tests. */
 void gxo_pong_render(double ball_x, double ball_y, double left_y, double right_y,
                      int left_score, int right_score, uint8_t* frame);
+
+/* Breakout raster alone (Envs.Breakout.cs:229-344).  bricks: bit row*18+col. */
+void gxo_breakout_render(double ball_x, double ball_y, double paddle_x, int ball_stuck, int score, int lives,
+                         const uint32_t bricks[4], uint8_t* frame);
 
 /* ---- CPU baseline: reference-shaped sequential loop over heap objects with a
  * virtual Step (VectorEnv.cs:28-34), single thread.  Runs `steps` batched

@@ -347,6 +347,107 @@ def pong_frame(bx, by, ly, ry, ls, rs):
     return np.repeat((m.astype(np.uint8) * 255).reshape(-1), 3)
 
 
+# ---------------------------------------------------------------- Breakout
+def breakout_unpack(words):
+    """int32 [4, N] brick words -> bool [N, 6, 18] (bit row*18+col)"""
+    w = np.asarray(words).astype(np.int64) & 0xFFFFFFFF
+    bits = np.arange(108)
+    return ((w[bits >> 5] >> (bits & 31)[:, None]) & 1).astype(bool).T.reshape(-1, 6, 18)
+
+
+def breakout_pack(bricks):
+    flat = np.asarray(bricks, bool).reshape(-1, 108)
+    out = np.zeros((4, flat.shape[0]), np.int64)
+    for b in range(108):
+        out[b >> 5] |= flat[:, b].astype(np.int64) << (b & 31)
+    return out.astype(np.uint32).view(np.int32)
+
+
+def breakout_step(st, ints, action, seed, env, tick):
+    """Envs.Breakout.cs:89-213.  st: float64 [5, N] (ballX, ballY, velX, velY,
+    paddleX); ints: int32 [8, N] (score, lives, stuck, 4 brick words, steps)."""
+    bx, by, vx, vy, px = (st[i].astype(f64).copy() for i in range(5))
+    score, lives = ints[0].astype(np.int32).copy(), ints[1].astype(np.int32).copy()
+    stuck = ints[2] != 0
+    bricks = breakout_unpack(ints[3:7])
+    steps = ints[7].astype(np.int32) + 1
+    a = np.asarray(action)
+    n = bx.shape[0]
+    fire = (a == 1) & stuck
+    vx = np.where(fire, (rng_uniform(seed, env, tick, 1, 0) - 0.5) * 2.0 * 3.0, vx)
+    vy = np.where(fire, -3.0, vy)
+    stuck = stuck & ~fire
+    px = np.where(a == 2, np.minimum(144.0, px + 5.0), np.where(a == 3, np.maximum(0.0, px - 5.0), px))
+    bx = np.where(((a == 2) | (a == 3)) & stuck, px + 8.0, bx)
+    mv = ~stuck
+    bx = np.where(mv, bx + vx, bx)
+    by = np.where(mv, by + vy, by)
+    wall = mv & ((bx <= 0) | (bx >= 158))
+    vx = np.where(wall, -vx, vx)
+    bx = np.where(wall, np.maximum(0.0, np.minimum(158.0, bx)), bx)
+    top = mv & (by <= 0)
+    vy = np.where(top, -vy, vy)
+    by = np.where(top, 0.0, by)
+    pad = mv & (by + 2 >= 190) & (by + 2 <= 194) & (bx + 2 >= px) & (bx <= px + 16)
+    vy = np.where(pad, -np.abs(vy), vy)
+    vx = np.where(pad, ((bx + 1.0) - (px + 8.0)) / 8.0 * 3.0 * 0.75, vx)
+    row = np.trunc((by - 60) / 6).astype(np.int64)
+    col = np.trunc(bx / 8).astype(np.int64)
+    inb = mv & (row >= 0) & (row < 6) & (col >= 0) & (col < 18)
+    idx = np.arange(n)
+    hit = inb & bricks[idx, np.clip(row, 0, 5), np.clip(col, 0, 17)]
+    bricks[idx[hit], row[hit], col[hit]] = False
+    vy = np.where(hit, -vy, vy)
+    reward = np.where(hit, (6 - row) + 1, 0).astype(f64)
+    score = score + reward.astype(np.int32)
+    fell = mv & (by > 210)
+    lives = lives - fell.astype(np.int32)
+    rs = fell & (lives > 0)
+    bx = np.where(rs, px + 8.0, bx)
+    by = np.where(rs, 180.0, by)
+    vx = np.where(rs, 0.0, vx)
+    vy = np.where(rs, 0.0, vy)
+    stuck = stuck | rs
+    gone = ~bricks.reshape(n, -1).any(axis=1)
+    reward = reward + np.where(gone, 100.0, 0.0)
+    done = (lives <= 0) | gone | (steps >= 10000)
+    new_ints = np.concatenate([np.stack([score, lives, stuck.astype(np.int32)]), breakout_pack(bricks), steps[None]])
+    return np.stack([bx, by, vx, vy, px]), new_ints.astype(np.int32), reward, done
+
+
+_BRICK_RGB = [(255, 0, 0), (255, 165, 0), (255, 255, 0), (0, 255, 0), (0, 0, 255), (128, 0, 128)]  # Envs.Breakout.cs:248-253
+
+
+def breakout_frame(bx, by, px, stuck, score, lives, words):
+    """Envs.Breakout.cs:229-344, painter's order kept: bricks, paddle, ball, score, lives."""
+    f = np.zeros((210, 160, 3), np.uint8)
+
+    def rect(x, y, w, h, rgb):
+        f[max(y, 0):max(min(y + h, 210), 0), max(x, 0):max(min(x + w, 160), 0)] = rgb
+
+    bricks = breakout_unpack(np.asarray(words, np.int64).reshape(4, 1).astype(np.uint32).view(np.int32))[0]
+    for r in range(6):
+        for c in range(18):
+            if bricks[r, c]:
+                rect(c * 8, 60 + r * 6, 7, 5, _BRICK_RGB[r])
+    white = (255, 255, 255)
+    rect(int(px), 190, 16, 4, white)
+    if not stuck:
+        rect(int(bx), int(by), 2, 2, white)
+    else:
+        rect(int(px + 8.0 - 1.0), 180, 2, 2, white)
+    for i, ch in enumerate(str(int(score))):
+        if not ch.isdigit():
+            continue
+        for dy, rowbits in enumerate(_GLYPHS[int(ch)]):
+            for dx, bit in enumerate(rowbits):
+                if bit == "1":
+                    rect(10 + i * 6 + dx, 10 + dy, 1, 1, white)
+    for i in range(int(lives)):
+        rect(10 + i * 8, 25, 6, 3, white)
+    return f.reshape(-1)
+
+
 # ---------------------------------------------------------------- wrappers
 class RecordEpisodeStatistics:
     """EnvWrapper.cs:23-58 for one env index; `step` takes the inner result."""

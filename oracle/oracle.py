@@ -12,7 +12,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libgym_oracle.so")
 
-CARTPOLE, MOUNTAINCAR, MOUNTAINCAR_CONT, PENDULUM, ACROBOT, FROZENLAKE, TAXI, CLIFFWALKING, PONG, DUMMY = range(10)
+(CARTPOLE, MOUNTAINCAR, MOUNTAINCAR_CONT, PENDULUM, ACROBOT, FROZENLAKE, TAXI, CLIFFWALKING, PONG, DUMMY,
+ BREAKOUT) = range(11)
 AUTORESET, RECORD_STATS, SLIPPERY, TAXI_FULL, ACROBOT_RK4 = 1, 2, 4, 8, 16
 PONG_FRAME_BYTES = 210 * 160 * 3
 FLOAT_ACTION = {MOUNTAINCAR_CONT, PENDULUM}
@@ -86,6 +87,7 @@ def lib():
     L.gxo_vec_episode_count.argtypes = [vp, u64]
     L.gxo_vec_episode_get.argtypes = [vp, u64, C.c_size_t, C.POINTER(dbl), C.POINTER(i32)]
     L.gxo_pong_render.argtypes = [dbl, dbl, dbl, dbl, C.c_int, C.c_int, vp]
+    L.gxo_breakout_render.argtypes = [dbl, dbl, dbl, C.c_int, C.c_int, C.c_int, vp, vp]
     L.gxo_bench_reference_shaped.restype = dbl
     L.gxo_bench_reference_shaped.argtypes = [C.c_int, u64, C.c_int, u64, C.POINTER(u64), C.POINTER(dbl)]
     _lib = L
@@ -176,7 +178,7 @@ class OracleVec:
         self.set_state_raw(np.concatenate([r, i]))
 
     def get_obs(self):
-        if self.env_id == PONG:
+        if self.env_id in (PONG, BREAKOUT):
             out = np.empty((self.n, PONG_FRAME_BYTES), np.uint8)
         elif self.n_real > 0:
             out = np.empty((self.obs_dim, self.n), np.float32)
@@ -223,6 +225,15 @@ def rng_below(seed, env, tick, stream, draw, n):
 def pong_render(ball_x, ball_y, left_y, right_y, left_score, right_score):
     out = np.empty(PONG_FRAME_BYTES, np.uint8)
     lib().gxo_pong_render(ball_x, ball_y, left_y, right_y, left_score, right_score, _ptr(out))
+    return out
+
+
+def breakout_render(ball_x, ball_y, paddle_x, ball_stuck, score, lives, bricks):
+    """bricks: four uint32 words, bit row*18+col"""
+    out = np.empty(PONG_FRAME_BYTES, np.uint8)
+    w = np.ascontiguousarray(bricks, dtype=np.uint32)
+    assert w.shape == (4,)
+    lib().gxo_breakout_render(ball_x, ball_y, paddle_x, int(ball_stuck), score, lives, _ptr(w), _ptr(out))
     return out
 
 

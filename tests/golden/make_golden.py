@@ -4,7 +4,8 @@ The reference is C# and cannot run here, and its own tests hold no numeric vecto
 envs, so these fixtures are outputs of the oracle (itself pinned by hand-derived known answers
 and by the independent numpy restatement).  Per env: 256 start states x 64 steps of random
 actions -- initial SoA state, the actions, every reward / done flag and the final state; for
-Pong additionally 8 frames as bit masks (a frame is 0/255 with equal channels).
+Pong additionally 8 frames as bit masks (a frame is 0/255 with equal channels), for Breakout
+as indices into its 8-colour palette.
 
     python tests/golden/make_golden.py
 """
@@ -18,18 +19,35 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 from oracle import oracle as O  # noqa: E402
 
 N, T, SEED = 256, 64, 20250614
+# black, white and the six brick rows (Envs.Breakout.cs:248-253)
+BREAKOUT_PALETTE = np.array([[0, 0, 0], [255, 255, 255], [255, 0, 0], [255, 165, 0], [255, 255, 0], [0, 255, 0], [0, 0, 255],
+                             [128, 0, 128]], np.uint8)
+
+
+def palette_index(frames):
+    """uint8 [k, 100800] HWC frames -> uint8 [k, 33600] palette indices (every pixel must be a palette colour)"""
+    px = frames.reshape(frames.shape[0], -1, 3).astype(np.int32)
+    key = (px[..., 0] << 16) | (px[..., 1] << 8) | px[..., 2]
+    pal = (BREAKOUT_PALETTE[:, 0].astype(np.int32) << 16) | (BREAKOUT_PALETTE[:, 1].astype(np.int32) << 8) | BREAKOUT_PALETTE[:, 2]
+    idx = np.full(key.shape, 255, np.uint8)
+    for i, c in enumerate(pal):
+        idx[key == c] = i
+    assert (idx != 255).all()
+    return idx
+
 CASES = [
     ("cartpole", O.CARTPOLE, 2, {}), ("mountaincar", O.MOUNTAINCAR, 3, {}), ("mountaincar_cont", O.MOUNTAINCAR_CONT, None, {}),
     ("pendulum", O.PENDULUM, None, {}), ("acrobot", O.ACROBOT, 3, {}), ("frozenlake", O.FROZENLAKE, 4, {}),
     ("frozenlake_8x8", O.FROZENLAKE, 4, {"map_rows": ["SFFFFFFF", "FFFFFFFF", "FFFHFFFF", "FFFFFHFF", "FFFHFFFF", "FHHFFFHF", "FHFFHFHF", "FFFHFFFG"]}),
     ("taxi", O.TAXI, 6, {}), ("cliffwalking", O.CLIFFWALKING, 4, {}), ("pong", O.PONG, 4, {}),
+    ("breakout", O.BREAKOUT, 4, {}),
 ]
 
 
 def main():
     for name, eid, nact, kw in CASES:
         rng = np.random.default_rng(sum(map(ord, name)))
-        steps = 400 if name == "pong" else T
+        steps = {"pong": 400, "breakout": 600}.get(name, T)
         v = O.OracleVec(eid, N, seed=SEED, **kw)
         v.reset()
         init = v.get_state_raw().copy()
@@ -46,11 +64,13 @@ def main():
                 f = v.get_obs()[:8]
                 assert ((f == 0) | (f == 255)).all() and (f[:, 0::3] == f[:, 1::3]).all() and (f[:, 0::3] == f[:, 2::3]).all()
                 frames.append(np.packbits(f[:, 0::3] == 255, axis=1))
+            if name == "breakout" and t % 150 == 149:
+                frames.append(palette_index(v.get_obs()[:8]))
         out = dict(init=init, actions=actions, rewards=rewards, dones=dones, final=v.get_state_raw(), seed=np.int64(SEED))
         if kw.get("map_rows"):
             out["map_rows"] = np.array("/".join(kw["map_rows"]))
         if frames:
-            out["frame_masks"] = np.stack(frames)
+            out["frame_index" if name == "breakout" else "frame_masks"] = np.stack(frames)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
         print(name, {k: getattr(x, "shape", None) for k, x in out.items()})
 

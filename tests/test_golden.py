@@ -1,6 +1,6 @@
 """Committed golden vectors (tests/golden/*.npz, made by tests/golden/make_golden.py from the
 oracle): the oracle must keep reproducing them (CPU), and the HIP path must reproduce them
-through the C ABI (GPU) -- bit-exact for tabular envs and Pong, and for the continuous envs too
+through the C ABI (GPU) -- bit-exact for tabular envs, Pong and Breakout, and for the continuous envs too
 unless a last-place double-precision trig difference flips a float rounding (then <= 1e-5)."""
 import glob
 import os
@@ -12,8 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 FILES = sorted(glob.glob(os.path.join(HERE, "golden", "*.npz")))
 ENV_OF = {"cartpole": "CARTPOLE", "mountaincar": "MOUNTAINCAR", "mountaincar_cont": "MOUNTAINCAR_CONT", "pendulum": "PENDULUM",
           "acrobot": "ACROBOT", "frozenlake": "FROZENLAKE", "frozenlake_8x8": "FROZENLAKE", "taxi": "TAXI",
-          "cliffwalking": "CLIFFWALKING", "pong": "PONG"}
-EXACT = {"frozenlake", "frozenlake_8x8", "taxi", "cliffwalking", "pong"}
+          "cliffwalking": "CLIFFWALKING", "pong": "PONG", "breakout": "BREAKOUT"}
+EXACT = {"frozenlake", "frozenlake_8x8", "taxi", "cliffwalking", "pong", "breakout"}
 
 
 def load(path):
@@ -23,8 +23,13 @@ def load(path):
     return name, z, rows
 
 
+def palette_index(frames):
+    from golden.make_golden import palette_index as f
+    return f(frames)
+
+
 def test_fixtures_present():
-    assert len(FILES) == 10
+    assert len(FILES) == 11
 
 
 @pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f)[:-4] for f in FILES])
@@ -34,10 +39,15 @@ def test_oracle_reproduces_golden(oracle, path):
     v = oracle.OracleVec(getattr(oracle, ENV_OF[name]), n, seed=int(z["seed"]), map_rows=rows)
     v.reset()
     assert np.array_equal(v.get_state_raw(), z["init"])
+    frames = []
     for t in range(z["actions"].shape[0]):
         r, d, _ = v.step(z["actions"][t])
         assert np.array_equal(r, z["rewards"][t]) and np.array_equal(d, z["dones"][t])
+        if name == "breakout" and t % 150 == 149:
+            frames.append(palette_index(v.get_obs()[:8]))
     assert np.array_equal(v.get_state_raw(), z["final"])
+    if frames:
+        assert np.array_equal(np.stack(frames), z["frame_index"])
 
 
 @pytest.mark.gpu
@@ -54,7 +64,7 @@ def test_gpu_reproduces_golden(path):
     frames = []
     mismatched = 0
     for t in range(z["actions"].shape[0]):
-        want_obs = name == "pong" and t % 50 == 49
+        want_obs = (name == "pong" and t % 50 == 49) or (name == "breakout" and t % 150 == 149)
         obs, r, d, _ = g.step_host(z["actions"][t], want_obs=want_obs)
         if name in EXACT:
             assert np.array_equal(r.astype(np.float64), z["rewards"][t]) and np.array_equal(d, z["dones"][t]), t
@@ -62,7 +72,9 @@ def test_gpu_reproduces_golden(path):
             bad = r.astype(np.float64) != z["rewards"][t]
             mismatched += int(bad.sum())
             assert np.allclose(r, z["rewards"][t], rtol=1e-5, atol=1e-6)
-        if want_obs:
+        if want_obs and name == "breakout":
+            frames.append(palette_index(obs[:8]))
+        elif want_obs:
             f = obs[:8]
             frames.append(np.packbits(f[:, 0::3] == 255, axis=1))
             assert ((f == 0) | (f == 255)).all() and (f[:, 0::3] == f[:, 1::3]).all() and (f[:, 0::3] == f[:, 2::3]).all()
@@ -77,4 +89,4 @@ def test_gpu_reproduces_golden(path):
         assert same or mismatched > 0 or np.allclose(a, b, rtol=1e-3, atol=1e-3), "state diverged"
         assert same, "golden continuous-control trajectory not bit-identical (%d reward mismatches)" % mismatched
     if frames:
-        assert np.array_equal(np.stack(frames), z["frame_masks"])
+        assert np.array_equal(np.stack(frames), z["frame_index" if name == "breakout" else "frame_masks"])

@@ -104,6 +104,38 @@ def test_pong_65536_frames(oracle):
     assert int(lit.min()) >= 27 * 8 + 2 * 30 - 8 and int(lit.max()) <= 27 * 8 + 60 + 4 + 2 * 2 * 15
 
 
+def test_breakout_65536_frames(oracle):
+    import torch
+    n, k, base, width = 65536, 120, 30000, 64
+    g = DeviceBatch(ctx(), L.ENV_BREAKOUT, n, seed=2, flags=L.AUTORESET | L.RECORD_STATS)
+    o = oracle.OracleVec(oracle.BREAKOUT, width, seed=2, flags=oracle.AUTORESET | oracle.RECORD_STATS, env_index_base=base)
+    g.reset(); o.reset()
+    for _ in range(k):
+        g.step_random(); o.step_random()
+    g.ctx.synchronize()
+    v = torch_views(g)
+    assert np.array_equal(v["obs"][base:base + width].cpu().numpy(), o.get_obs())
+    f = v["obs"].view(n, 210, 160, 3)
+    st = v["state_int"]
+    # conservation: score == sum over rows of (bricks broken in the row) x (row value); 5 lives or fewer
+    words = st[3:7, :n].to(torch.int64) & 0xFFFFFFFF
+    score = torch.zeros(n, dtype=torch.int64, device=words.device)
+    for row in range(6):
+        for col in range(18):
+            bit = row * 18 + col
+            present = (words[bit >> 5] >> (bit & 31)) & 1
+            score += (1 - present) * (7 - row)
+    assert torch.equal(score, st[0, :n].to(torch.int64))
+    assert int(st[1, :n].max()) <= 5 and int(st[1, :n].min()) >= 1
+    # brick pixels: every brick-row pixel is black, white (the ball) or that row's colour
+    rgb = [(255, 0, 0), (255, 165, 0), (255, 255, 0), (0, 255, 0), (0, 0, 255), (128, 0, 128)]
+    for row in range(6):
+        band = f[:, 60 + 6 * row:66 + 6 * row].reshape(-1, 3).to(torch.int32)
+        code = (band[:, 0] << 16) | (band[:, 1] << 8) | band[:, 2]
+        ok = (code == 0) | (code == 0xFFFFFF) | (code == ((rgb[row][0] << 16) | (rgb[row][1] << 8) | rgb[row][2]))
+        assert bool(ok.all()), row
+
+
 def test_acrobot_16mi_window_and_rk4_rollout(oracle):
     g, v = _window_matches_oracle(oracle, L.ENV_ACROBOT, N16, base=1 << 23, width=2048, k=6, seed=4, flags=FUSED)
     g.close()

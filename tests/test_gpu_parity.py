@@ -42,7 +42,7 @@ def compare_step(g, o, a, t, exact):
     return n
 
 
-@pytest.mark.parametrize("env_id", CLASSIC + TABULAR + [L.ENV_PONG])
+@pytest.mark.parametrize("env_id", CLASSIC + TABULAR + [L.ENV_PONG, L.ENV_BREAKOUT])
 def test_reset_matches_oracle(oracle, env_id):
     g, o = make_pair(oracle, env_id, 1000, seed=77, base=5)
     g.reset(); o.reset()
@@ -51,7 +51,7 @@ def test_reset_matches_oracle(oracle, env_id):
     g.reset(); o.reset()  # second reset uses a new tick, hence new draws
     gr2, _ = g.get_state(); orr2, _ = o.get_state()
     assert np.array_equal(bits(gr2), bits(orr2))
-    if gr.size and env_id not in (L.ENV_PONG,):
+    if gr.size and env_id not in (L.ENV_PONG, L.ENV_BREAKOUT):
         assert not np.array_equal(gr, gr2)
     assert np.array_equal(bits(g.get_obs()), bits(o.get_obs()))
 
@@ -197,7 +197,67 @@ def test_pong_frames_edge_states(oracle):
     assert np.array_equal(g.get_obs(), o.get_obs())
 
 
-@pytest.mark.parametrize("env_id", [L.ENV_CARTPOLE, L.ENV_PENDULUM, L.ENV_CLIFFWALKING, L.ENV_PONG, L.ENV_DUMMY])
+def _breakout_actions(rng, g, n):
+    """half the envs act at random (with out-of-range actions), the others fire and follow the ball"""
+    reals, ints = g.get_state()
+    a = rng.integers(-1, 6, n).astype(np.int32)
+    track = np.where(ints[2] != 0, 1, np.where(reals[0] + 1 > reals[4] + 10, 2, np.where(reals[0] + 1 < reals[4] + 6, 3, 0)))
+    a[n // 2:] = track[n // 2:]
+    return a
+
+
+def test_breakout_state_and_frames_bit_exact(oracle):
+    n, steps = 257, 1400
+    g, o = make_pair(oracle, L.ENV_BREAKOUT, n, seed=8)
+    assert np.array_equal(g.get_obs(), o.get_obs())  # the constructor resets (Envs.Breakout.cs:54-60)
+    g.reset(); o.reset()
+    assert np.array_equal(g.get_obs(), o.get_obs())
+    rng = np.random.default_rng(4)
+    total = np.zeros(n)
+    for t in range(steps):
+        a = _breakout_actions(rng, g, n)
+        obs, rew, done, _ = g.step_host(a, want_obs=(t % 100 == 0))
+        orew, odone, _ = o.step(a)
+        assert np.array_equal(rew.astype(np.float64), orew) and np.array_equal(done, odone), t
+        total += orew
+        if obs is not None:
+            assert np.array_equal(obs, o.get_obs()), "frames differ at step %d" % t
+    gr, gi = g.get_state(); orr, oi = o.get_state()
+    assert np.array_equal(bits(gr), bits(orr)) and np.array_equal(gi, oi)
+    assert total.max() > 100 and (gi[1] <= 0).any() and (gi[1] > 0).any()  # long rallies and lost games both occurred
+    assert np.array_equal(g.get_obs(), o.get_obs())
+
+
+def test_breakout_win_and_edge_frames(oracle):
+    """the last brick pays its row value + 100 and ends the game (Envs.Breakout.cs:182-199); frames at edge states"""
+    full = [-1, -1, -1, 0xFFF]
+    #        ballX  ballY velX velY paddleX | score lives stuck b0 b1 b2 b3 steps
+    cases = [
+        [43.0, 79.0, 0.5, -3.0, 72.0, 0, 5, 0, 0, 1 << 9, 0, 0, 3],          # about to enter the last brick (row 2, col 5)
+        [43.0, 79.0, 0.5, -3.0, 72.0, 0, 5, 0, 1, 1 << 9, 0, 0, 3],          # same, another brick remains
+        [0.0, 0.0, -3, -3, 0.0, 0, 5, 0] + full + [0], [158.9, 209.5, 3, 3, 144.0, 486, 1, 0, 0, 0, 0, 0, 9],
+        [80.0, 180.0, 0, 0, 72.0, 7, 5, 1] + full + [1], [12.3, 11.7, 1, 1, 143.9, 1234567890, 9, 0, 0x12345678, -1698898192, 0x0F0F0F0F, 0xA5A, 5],
+        [10.0, 25.0, 0, 0, 3.5, -42, 0, 1] + full + [2], [75.5, 250.0, 0, 3, 20.0, 99, -1, 0, 1, 0, 0, 0x800, 4],
+        [3.0, 62.0, 1, -3, 0.0, 10, 30, 0] + full + [6], [100.0, 208.5, 0.2, 3.0, 90.0, 0, 1, 0] + full + [9999],
+    ]
+    cases = np.array(cases, np.float64)
+    n = len(cases)
+    g, o = make_pair(oracle, L.ENV_BREAKOUT, n)
+    reals = cases[:, :5].T.copy()
+    ints = cases[:, 5:].T.astype(np.int64).astype(np.int32).copy()
+    g.set_state(reals, ints); o.set_state(reals, ints)
+    assert np.array_equal(g.get_obs(), o.get_obs())
+    a = np.zeros(n, np.int32)
+    obs, rew, done, _ = g.step_host(a, want_obs=True)
+    orew, odone, _ = o.step(a)
+    assert rew[0] == 105.0 and done[0] == 1 and rew[1] == 5.0 and done[1] == 0
+    assert np.array_equal(rew.astype(np.float64), orew) and np.array_equal(done, odone)
+    gr, gi = g.get_state(); orr, oi = o.get_state()
+    assert np.array_equal(bits(gr), bits(orr)) and np.array_equal(gi, oi)
+    assert np.array_equal(obs, o.get_obs())
+
+
+@pytest.mark.parametrize("env_id", [L.ENV_CARTPOLE, L.ENV_PENDULUM, L.ENV_CLIFFWALKING, L.ENV_PONG, L.ENV_DUMMY, L.ENV_BREAKOUT])
 @pytest.mark.parametrize("flags,time_limit", [(L.AUTORESET | L.RECORD_STATS, 0), (L.RECORD_STATS, 17), (L.AUTORESET | L.RECORD_STATS, 9), (L.AUTORESET, 0)])
 def test_fused_wrappers(oracle, env_id, flags, time_limit):
     """auto-reset, TimeLimit (Wrappers.TimeLimit.cs) and RecordEpisodeStatistics (EnvWrapper.cs:23-58) fused in the step"""
@@ -205,7 +265,7 @@ def test_fused_wrappers(oracle, env_id, flags, time_limit):
     g, o = make_pair(oracle, env_id, n, seed=13, flags=flags, time_limit=time_limit, base=1 << 33)
     g.reset(); o.reset()
     rng = np.random.default_rng(6)
-    exact = env_id in (L.ENV_CLIFFWALKING, L.ENV_PONG, L.ENV_DUMMY)
+    exact = env_id in (L.ENV_CLIFFWALKING, L.ENV_PONG, L.ENV_DUMMY, L.ENV_BREAKOUT)
     for t in range(steps):
         a = random_actions(rng, env_id, n)
         obs, rew, done, trunc = g.step_host(a, want_trunc=time_limit > 0)
@@ -233,7 +293,7 @@ def test_fused_wrappers(oracle, env_id, flags, time_limit):
             assert gs.min_return == os_.min_return and gs.max_return == os_.max_return
 
 
-@pytest.mark.parametrize("env_id", CLASSIC + [L.ENV_FROZENLAKE, L.ENV_TAXI, L.ENV_PONG])
+@pytest.mark.parametrize("env_id", CLASSIC + [L.ENV_FROZENLAKE, L.ENV_TAXI, L.ENV_PONG, L.ENV_BREAKOUT])
 def test_random_policy_and_rollout(oracle, env_id):
     """actions sampled on the device (Spaces.Discrete.cs:18 / Spaces.Box.cs:25-33) and K fused steps"""
     n, k = 2051, 24
@@ -251,7 +311,7 @@ def test_random_policy_and_rollout(oracle, env_id):
     assert np.array_equal(bits(gr), bits(g2r)) and np.array_equal(gi, g2i)
     s1, s2, so = g.stats(), g2.stats(), o.stats()
     assert s1.episodes == s2.episodes and s1.sum_length == s2.sum_length
-    if env_id in (L.ENV_FROZENLAKE, L.ENV_TAXI, L.ENV_PONG):
+    if env_id in (L.ENV_FROZENLAKE, L.ENV_TAXI, L.ENV_PONG, L.ENV_BREAKOUT):
         assert np.array_equal(bits(gr), bits(orr)) and np.array_equal(gi, oi)
         assert s1.episodes == so.episodes and s1.sum_return == so.sum_return and s1.sum_length == so.sum_length
     else:

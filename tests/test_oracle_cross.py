@@ -127,6 +127,73 @@ def test_pong_frames_edge_cases(oracle):
         assert np.array_equal(oracle.pong_render(*c), NP.pong_frame(*c)), c
 
 
+def _breakout_policy(rng, st, ints):
+    """half the envs act at random, the others fire and then follow the ball (long rallies)"""
+    n = st.shape[1]
+    a = rng.integers(0, 4, n).astype(np.int32)
+    track = np.where(ints[2] != 0, 1, np.where(st[0] + 1 > st[4] + 10, 2, np.where(st[0] + 1 < st[4] + 6, 3, 0)))
+    a[n // 2:] = track[n // 2:]
+    return a
+
+
+def test_breakout_bitwise(oracle):
+    n = 256
+    v = oracle.OracleVec(oracle.BREAKOUT, n, seed=SEED)
+    v.reset()
+    env = np.arange(n, dtype=np.uint64)
+    st = np.stack([np.full(n, 80.0), np.full(n, 180.0), np.zeros(n), np.zeros(n), np.full(n, 72.0)])
+    ints = np.zeros((8, n), np.int32)
+    ints[1] = 5; ints[2] = 1
+    ints[3:7] = NP.breakout_pack(np.ones((n, 6, 18), bool))
+    reals, i0 = v.get_state()
+    assert np.array_equal(bits(reals), bits(st)) and np.array_equal(i0, ints)  # Envs.Breakout.cs:62-87
+    rng = np.random.default_rng(4)
+    total = np.zeros(n)
+    for t in range(1500):
+        a = _breakout_policy(rng, st, ints)
+        rew, done, _ = v.step(a)
+        st, ints, rew2, done2 = NP.breakout_step(st, ints, a, SEED, env, t + 1)
+        reals, i0 = v.get_state()
+        assert np.array_equal(bits(reals), bits(st)), t
+        assert np.array_equal(i0, ints) and np.array_equal(rew, rew2) and np.array_equal(done.astype(bool), done2), t
+        total += rew
+        if t % 250 == 249:
+            frames = v.get_obs()
+            for i in range(0, n, 31):
+                exp = NP.breakout_frame(st[0, i], st[1, i], st[4, i], ints[2, i], ints[0, i], ints[1, i], ints[3:7, i])
+                assert np.array_equal(frames[i], exp), (t, i)
+    assert np.array_equal(total, ints[0])  # info["score"] accumulates the rewards (Envs.Breakout.cs:162-163)
+    assert (ints[1] <= 0).any() and (ints[1] > 0).any() and ints[0].max() > 100
+
+
+def test_breakout_win_and_edge_frames(oracle):
+    """last brick: reward 100 + row value and done (Envs.Breakout.cs:182-199); frames at edge states"""
+    v = oracle.OracleVec(oracle.BREAKOUT, 2, seed=1)
+    v.reset()
+    reals, ints = v.get_state()
+    reals = reals.copy(); ints = ints.copy()
+    one = np.zeros((2, 6, 18), bool)
+    one[0, 2, 5] = True            # env 0: the ball is about to enter this brick
+    one[1, 2, 5] = True; one[1, 0, 0] = True
+    ints[3:7] = NP.breakout_pack(one)
+    ints[2] = 0
+    reals[0] = 5 * 8 + 3.0; reals[1] = 60 + 3 * 6 + 1.0; reals[2] = 0.5; reals[3] = -3.0
+    v.set_state(reals, ints)
+    rew, done, _ = v.step(np.zeros(2, np.int32))
+    assert rew.tolist() == [105.0, 5.0] and done.tolist() == [1, 0]
+    st2, i2, rew2, done2 = NP.breakout_step(reals, ints, np.zeros(2, np.int32), 1, np.arange(2, dtype=np.uint64), 1)
+    r1, i1 = v.get_state()
+    assert np.array_equal(bits(r1), bits(st2)) and np.array_equal(i1, i2) and np.array_equal(rew, rew2)
+    full = [0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFF]
+    cases = [
+        (0.0, 0.0, 0.0, 0, 0, 5, full), (158.9, 209.5, 144.0, 0, 486, 1, [0, 0, 0, 0]), (80.0, 180.0, 72.0, 1, 7, 5, full),
+        (12.3, 11.7, 143.9, 0, 1234567890, 9, [0x12345678, 0x9ABCDEF0, 0x0F0F0F0F, 0xA5A]), (10.0, 25.0, 3.5, 1, -42, 0, full),
+        (75.5, 250.0, 20.0, 0, 99, -1, [1, 0, 0, 0x800]), (3.0, 62.0, 0.0, 0, 10, 30, full),
+    ]
+    for c in cases:
+        assert np.array_equal(oracle.breakout_render(*c), NP.breakout_frame(*c)), c
+
+
 def test_wrappers_match_numpy_restatement(oracle):
     """RecordEpisodeStatistics(TimeLimit(CartPole)) without autoreset, stepping past done."""
     n = 64
