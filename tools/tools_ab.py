@@ -19,4 +19,4 @@ for r in range(rounds):
             res[v].append(None); print(v, p.stderr[-500:], flush=True)
 for v in args:
     xs = [x for x in res[v] if x]
-    print("%-12s ms: %s  best GB/s %.0f" % (v, ["%.4f" % x for x in xs], (57 * (1 << 24) / (min(xs) * 1e-3) / 1e9) if xs else 0), flush=True)
+    print("%-12s kernel ms per step: %s  best %.4f" % (v, ["%.4f" % x for x in xs], min(xs) if xs else 0), flush=True)
