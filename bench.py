@@ -53,6 +53,10 @@ FRAME_ENVS = ("pong", "breakout")
 # ~32 flops, 52 for the RK4 combination, ~16 for wrap/clamp/termination),
 # transcendentals not counted
 ACROBOT_RK4_FLOPS = 196
+# the same per env-step as the hardware counts it, sin/cos polynomials and reciprocals included:
+# (SQ_INSTS_VALU_ADD_F64 + MUL_F64 + TRANS_F64 + 2 FMA_F64) x 64 lanes / (envs x K) of the fused
+# 64-step rollout, profiles/r1/fp64_valu_acrobot_rk4_rollout64.json
+ACROBOT_RK4_FLOPS_COUNTED = 729.5
 
 
 def time_steps(batch, step_fn, steps, warmup, dist):
@@ -112,6 +116,10 @@ def main():
     ap.add_argument("--num-envs", type=int, default=0, help="envs per GPU (default 16 Mi; Pong, Breakout 65536)")
     ap.add_argument("--policy", default="device", choices=["device", "random"])
     ap.add_argument("--mode", default="exact", choices=["exact", "fast32"])
+    ap.add_argument("--rk4", action="store_true", help="Acrobot only: the RK4 / binary64 extension (upstream dynamics)")
+    ap.add_argument("--rollout", type=int, default=1,
+                    help="K > 1: every timed step is one fused K-step rollout launch (state stays in registers, "
+                         "actions sampled in-kernel); env-steps are counted as envs x K per launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary Acrobot measurements")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -145,6 +153,13 @@ def main():
     torch.cuda.set_stream(torch.cuda.Stream())
     ctx = Context(local_rank)
     flags = L.AUTORESET | L.RECORD_STATS
+    if args.rk4:
+        if args.env != "acrobot":
+            ap.error("--rk4 applies to --env acrobot")
+        flags |= L.ACROBOT_RK4
+    k_roll = max(1, args.rollout)
+    if k_roll > 1:
+        args.policy = "random"
     mode = L.MODE_EXACT if args.mode == "exact" else L.MODE_FAST32
     # weak scaling: every rank owns n envs of the n * world batch, keyed by global env index
     base, n_local = shard(n * world, rank, world)
@@ -154,7 +169,9 @@ def main():
     batch.reset()
     stream_ptr = torch.cuda.current_stream().cuda_stream
     view = batch.view()
-    if args.policy == "device":
+    if k_roll > 1:
+        step_fn = lambda: batch.rollout(k_roll, L.POLICY_RANDOM, None, stream_ptr)  # noqa: E731
+    elif args.policy == "device":
         adt = torch.float32 if batch.info.action_dtype == L.F32 else torch.int32
         actions = torch.empty(int(view.stride), dtype=adt, device="cuda")
         batch.sample_actions(0, actions.data_ptr(), stream_ptr)
@@ -164,19 +181,29 @@ def main():
     torch.cuda.synchronize()
 
     wall, kernel_ms = time_steps(batch, step_fn, args.steps, args.warmup, dist)
-    total_steps = n * world * args.steps
+    total_steps = n * world * args.steps * k_roll
     value = total_steps / wall
 
-    b_alg = B_ALG[args.env] - (4 if args.policy == "random" else 0)
+    if args.rk4:
+        # f64 state r+w, steps r+w, ep_return r+w, reward, done, derived f32 observation rows
+        b_alg = 32 + 32 + 4 + 4 + 4 + 4 + 4 + 1 + 24
+    else:
+        b_alg = B_ALG[args.env] - (4 if args.policy == "random" else 0)
     achieved = b_alg * n / (kernel_ms * 1e-3) / 1e9
+    if k_roll > 1:
+        kind = "fused %d-step rollout kernel (one launch per timed step)" % k_roll
+    else:
+        kind = "single-step kernel"
+    name = args.env + (" RK4/fp64" if args.rk4 else "")
     out = {
         "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "u8" if args.env in FRAME_ENVS else ("i32" if args.env == "frozenlake" else "f32"),
+        "vs_baseline": None,
+        "dtype": "f64" if args.rk4 else "u8" if args.env in FRAME_ENVS else ("i32" if args.env == "frozenlake" else "f32"),
         "data": "synthetic",
         "config": {
-            "workload": "%s VectorEnv.Step, %d envs/GPU, single-step kernel, auto-reset + RecordEpisodeStatistics fused, "
-                        "%s, %s mode" % (args.env, n, "device-resident random actions (zero-copy path)"
+            "workload": "%s VectorEnv.Step, %d envs/GPU, %s, auto-reset + RecordEpisodeStatistics fused, "
+                        "%s, %s mode" % (name, n, kind, "device-resident random actions (zero-copy path)"
                                          if args.policy == "device" else "actions sampled in-kernel", args.mode),
             "envs_per_gpu": n, "sharding": "independent env shards, no data-path collective",
         },
@@ -185,6 +212,15 @@ def main():
                      "kernel_ms": kernel_ms, "bytes_per_env_step": b_alg,
                      "algorithmic_bytes_per_launch": b_alg * n},
     }
+    if args.rk4 and k_roll > 1:
+        # the fused rollout is bound by the FP64 vector ALU, not by HBM: flops as the SQ counters
+        # count them per env-step x env-steps per launch / live launch time
+        tf = n * k_roll * ACROBOT_RK4_FLOPS_COUNTED / (kernel_ms * 1e-3) / 1e12
+        out["roofline"] = {"bound": "fp64-valu", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": tf / FP64_VALU_PEAK_TFLOPS, "traffic": None, "kernel_ms": kernel_ms,
+                           "fp64_flops_per_env_step": ACROBOT_RK4_FLOPS_COUNTED,
+                           "arithmetic_only_flops_per_env_step": ACROBOT_RK4_FLOPS,
+                           "source": "SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64, profiles/r1/fp64_valu_acrobot_rk4_rollout64.json"}
     # HBM bytes per launch from the rocprofv3 counter passes (FETCH_SIZE doubled as gfx950
     # needs, WRITE_SIZE as read) of this same command, taken by tools/collect_profiles.sh and
     # committed under profiles/; counters cannot be read from inside this process.
@@ -192,7 +228,7 @@ def main():
     if os.path.exists(traffic_file) and world == 1:
         try:
             t = json.load(open(traffic_file)).get("%s:%d:%s" % (args.env, n, args.policy))
-            if t:
+            if t and not args.rk4 and k_roll == 1:
                 out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
                 out["roofline"]["traffic_source"] = t["source"]
         except (OSError, ValueError, KeyError):
@@ -232,8 +268,9 @@ def extra_measurements(ctx, n, stream_ptr):
     _, ms = time_steps(b, lambda: b.rollout(k, L.POLICY_RANDOM, None, stream_ptr), 3, 1, None)
     rate = n * k / (ms * 1e-3)
     res["acrobot_rk4_fp64_rollout64"] = {"env_steps_per_s": rate, "kernel_ms": ms,
-                                         "fp64_TFLOPs_arith_only": rate * ACROBOT_RK4_FLOPS / 1e12,
-                                         "frac_of_fp64_valu_peak_arith_only": rate * ACROBOT_RK4_FLOPS / 1e12 / FP64_VALU_PEAK_TFLOPS}
+                                         "fp64_TFLOPs": rate * ACROBOT_RK4_FLOPS_COUNTED / 1e12,
+                                         "frac_of_fp64_valu_peak": rate * ACROBOT_RK4_FLOPS_COUNTED / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                                         "fp64_TFLOPs_arith_only": rate * ACROBOT_RK4_FLOPS / 1e12}
     b.close()
     return res
 

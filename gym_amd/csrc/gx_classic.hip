@@ -303,8 +303,19 @@ struct Acrobot {
     s[0] = c1n; s[1] = s1n; s[2] = c2n; s[3] = s2n; s[4] = dtheta1; s[5] = dtheta2;
     steps++;
 
-    float tip_y = -LINK_LENGTH_1 * c1n - LINK_LENGTH_2 * T::cos(theta1 + theta2);
-    done = tip_y > 1.0f || steps >= 500;
+    // tip_y = -cos(theta1) - cos(theta1 + theta2) is only compared with 1 (Envs.Acrobot.cs:80-81).
+    // The addition formula on the float sines and cosines is within 2e-6 of it (their roundings
+    // plus the rounding of the float sum theta1 + theta2, below 16 in magnitude), so only a tip
+    // within 1e-5 of the threshold needs the expression evaluated as the source writes it.
+    bool above;
+    if (MODE == GX_MODE_EXACT) {
+      const float tip_approx = -c1n - (c1n * c2n - s1n * s2n);
+      above = tip_approx > 1.0f;
+      if (fabsf(tip_approx - 1.0f) < 1e-5f) above = -LINK_LENGTH_1 * c1n - LINK_LENGTH_2 * T::cos(theta1 + theta2) > 1.0f;
+    } else {
+      above = -LINK_LENGTH_1 * c1n - LINK_LENGTH_2 * T::cos(theta1 + theta2) > 1.0f;
+    }
+    done = above || steps >= 500;
     reward = done ? 0.0f : -1.0f;
   }
   static __device__ __forceinline__ Act sample(const Draws& d) { return d.below(0, NACT); }
