@@ -7,13 +7,16 @@
 // one RK4 step of dt = 0.2, both angles wrapped to [-pi, pi], velocity bounds
 // 4pi / 9pi, terminal when -cos(t1) - cos(t1 + t2) > 1 or after 500 steps.
 // It is the FP64 vector-ALU workload: in a K-step rollout the state never
-// leaves registers.  Two envs per lane (16 bytes of each double row).
+// leaves registers.  Two envs per lane (16 bytes of each double row).  While an
+// env is in registers the sines and cosines of its two angles ride along with
+// the state: the termination test of one step, the first RK4 stage of the next
+// and the observation all need exactly those four values.
 //
 // Every a*b+c is an explicit fma() (and nothing else is contracted) so that a
 // CPU restatement written with the same fma() calls can match wherever the
 // sin/cos results agree; sin and cos come from the reduction-light binary64
-// routine of gx_math.h (last-place accurate, so results differ from a libm
-// build by parts in 10^16).
+// routine of gx_math.h (a few units in the last place, so results differ from
+// a libm build by parts in 10^16).
 #pragma clang fp contract(off)
 
 #include "gx_classic_kernel.h"
@@ -22,6 +25,7 @@ namespace gx {
 
 struct Acrobot64 {
   static constexpr int NS = 4;
+  static constexpr int NR = 8;  // + sin(theta1), cos(theta1), sin(theta2), cos(theta2) of the current state
   using Real = double;
   static constexpr int W = 2;
   static constexpr bool kDerivedObs = true;
@@ -36,10 +40,16 @@ struct Acrobot64 {
   // every sin/cos argument of an RK4 stage stays below 16 for any finite state
   static constexpr bool kAlwaysBounded = true;
 
-  static __device__ __forceinline__ void reset(double (&s)[NS], const RngKey& key, uint64_t env) {
+  static __device__ __forceinline__ void derive(double (&s)[NR]) {
+    math::sincos_reduced(s[0], s[4], s[5]);
+    math::sincos_reduced(s[1], s[6], s[7]);
+  }
+
+  static __device__ __forceinline__ void reset(double (&s)[NR], const RngKey& key, uint64_t env) {
     Draws d = philox_block(key, env, 0, 0);
 #pragma unroll
     for (int i = 0; i < 4; i++) s[i] = fma(d.uniform(i), 0.2, -0.1);
+    derive(s);
   }
 
   // 1/x to the last place or two: hardware estimate plus two Newton steps (this extension is
@@ -55,11 +65,14 @@ struct Acrobot64 {
   // equations' cos(theta1 - pi/2) is sin(theta1) and cos(theta1 + theta2 - pi/2) is
   // sin(theta1 + theta2) = s1 c2 + c1 s2.
   static __device__ __forceinline__ void dsdt(const double (&y)[4], double u, double (&dy)[4]) {
-    const double g = 9.8;
-    const double t1 = y[0], t2 = y[1], w1 = y[2], w2 = y[3];
     double s1, c1, s2, c2;
-    math::sincos_bounded(t1, s1, c1);
-    math::sincos_bounded(t2, s2, c2);
+    math::sincos_reduced(y[0], s1, c1);
+    math::sincos_reduced(y[1], s2, c2);
+    dsdt(y[2], y[3], s1, c1, s2, c2, u, dy);
+  }
+  static __device__ __forceinline__ void dsdt(double w1, double w2, double s1, double c1, double s2, double c2, double u,
+                                              double (&dy)[4]) {
+    const double g = 9.8;
     const double s12 = fma(s1, c2, c1 * s2);
     const double d1 = c2 + 3.5;
     const double d2 = fma(0.5, c2, 1.25);
@@ -85,11 +98,11 @@ struct Acrobot64 {
   }
 
   template <int MODE, bool BOUNDED>
-  static __device__ __forceinline__ void step(double (&s)[NS], int32_t& steps, Act action, Rew& reward, bool& done) {
+  static __device__ __forceinline__ void step(double (&s)[NR], int32_t& steps, Act action, Rew& reward, bool& done) {
     const double dt = 0.2;
     const double u = action == 0 ? -1.0 : (action == 2 ? 1.0 : 0.0);
     double k1[4], k2[4], k3[4], k4[4], y[4];
-    dsdt(s, u, k1);
+    dsdt(s[2], s[3], s[4], s[5], s[6], s[7], u, k1);
 #pragma unroll
     for (int i = 0; i < 4; i++) y[i] = fma(0.5 * dt, k1[i], s[i]);
     dsdt(y, u, k2);
@@ -113,21 +126,17 @@ struct Acrobot64 {
 #pragma unroll
     for (int i = 0; i < 4; i++) s[i] = y[i];
     steps++;
-    double sa, ca, sb, cb;
-    math::sincos_bounded(y[0], sa, ca);
-    math::sincos_bounded(y[1], sb, cb);
+    derive(s);
+    const double sa = s[4], ca = s[5], sb = s[6], cb = s[7];
     // -cos(t1) - cos(t1 + t2), the second by the angle-addition formula
     done = (-ca - fma(ca, cb, -(sa * sb)) > 1.0) || steps >= 500;
     reward = done ? 0.0f : -1.0f;
   }
 
   // the reference's observation layout (Envs.Acrobot.cs:77-82)
-  static __device__ __forceinline__ void observe(const double (&s)[NS], float (&o)[NOBS]) {
-    double sn, cs;
-    math::sincos_bounded(s[0], sn, cs);
-    o[0] = (float)cs; o[1] = (float)sn;
-    math::sincos_bounded(s[1], sn, cs);
-    o[2] = (float)cs; o[3] = (float)sn;
+  static __device__ __forceinline__ void observe(const double (&s)[NR], float (&o)[NOBS]) {
+    o[0] = (float)s[5]; o[1] = (float)s[4];
+    o[2] = (float)s[7]; o[3] = (float)s[6];
     o[4] = (float)s[2];
     o[5] = (float)s[3];
   }

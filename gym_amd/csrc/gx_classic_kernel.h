@@ -17,6 +17,8 @@
 //             can then grow without bound.
 #pragma once
 
+#include <type_traits>
+
 #include "gx_device.h"
 #include "gx_launch.h"
 #include "gx_trig.h"
@@ -129,6 +131,18 @@ struct ThreadStats<double> {
 };
 
 // ---------------------------------------------------------------- kernels ---
+// An env may keep derived quantities next to its stored state while it is in registers: E::NR
+// (>= E::NS) values per env, of which the first NS are the rows in memory and the rest are
+// recomputed by E::derive() after a load (E::reset() fills them itself).
+template <class E, class = void>
+struct RegState {
+  static constexpr int value = E::NS;
+};
+template <class E>
+struct RegState<E, std::void_t<decltype(E::NR)>> {
+  static constexpr int value = E::NR;
+};
+
 // minimum resident waves per SIMD the fused kernels are compiled for (caps their registers)
 #ifndef GX_FUSED_MIN_WAVES
 #define GX_FUSED_MIN_WAVES 1
@@ -141,6 +155,7 @@ __global__ void __launch_bounds__(kBlock, (FUSED && BOUNDED) ? GX_FUSED_MIN_WAVE
   using Rew = typename E::Rew;
   using EpRet = typename E::EpRet;
   constexpr int NS = E::NS;
+  constexpr int NR = RegState<E>::value;
   constexpr int W = E::W;
 
   const bool autoreset = FUSED ? true : (a.flags & GX_AUTORESET) != 0;
@@ -157,7 +172,7 @@ __global__ void __launch_bounds__(kBlock, (FUSED && BOUNDED) ? GX_FUSED_MIN_WAVE
     // consecutive launches sweep the batch in opposite directions: the rows a sweep touched
     // last are still in the 256 MiB memory-side cache when the next sweep starts there
     const uint64_t q = a.reverse ? ngroups - 1 - it : it;
-    Real s[W][NS];
+    Real s[W][NR];
     int32_t steps[W];
     EpRet ep_ret[W] = {};
     int32_t ep_len[W] = {};
@@ -167,6 +182,10 @@ __global__ void __launch_bounds__(kBlock, (FUSED && BOUNDED) ? GX_FUSED_MIN_WAVE
       load_row<Real, W>(sreal + (uint64_t)c * a.stride, q, v);
 #pragma unroll
       for (int j = 0; j < W; j++) s[j][c] = v[j];
+    }
+    if constexpr (NR > NS) {
+#pragma unroll
+      for (int j = 0; j < W; j++) E::derive(s[j]);
     }
     load_row<int32_t, W>(steps_row, q, steps);
     if (record) {
@@ -212,13 +231,13 @@ __global__ void __launch_bounds__(kBlock, (FUSED && BOUNDED) ? GX_FUSED_MIN_WAVE
         while (__any(pending != 0)) {
           if (pending) {
             const int jj = __ffs((int)pending) - 1;
-            Real fresh[NS];
+            Real fresh[NR];
             E::reset(fresh, key, env0 + (uint64_t)jj);
 #pragma unroll
             for (int j = 0; j < W; j++) {
               if (jj == j) {
 #pragma unroll
-                for (int c = 0; c < NS; c++) s[j][c] = fresh[c];
+                for (int c = 0; c < NR; c++) s[j][c] = fresh[c];
                 steps[j] = 0;
               }
             }
@@ -266,12 +285,13 @@ template <class E>
 __global__ void __launch_bounds__(kBlock) classic_reset_kernel(StepArgs a, int only_observe) {
   using Real = typename E::Real;
   constexpr int NS = E::NS;
+  constexpr int NR = RegState<E>::value;
   constexpr int W = E::W;
   Real* const sreal = static_cast<Real*>(a.state_real);
   const RngKey key = make_key(a.seed_lo, a.seed_hi, a.tick);
   const uint64_t ngroups = (a.num_envs + (W - 1)) / W;
   for (uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q < ngroups; q += (uint64_t)gridDim.x * kBlock) {
-    Real s[W][NS];
+    Real s[W][NR];
     if (only_observe) {
 #pragma unroll
       for (int c = 0; c < NS; c++) {
@@ -279,6 +299,10 @@ __global__ void __launch_bounds__(kBlock) classic_reset_kernel(StepArgs a, int o
         load_row<Real, W>(sreal + (uint64_t)c * a.stride, q, v);
 #pragma unroll
         for (int j = 0; j < W; j++) s[j][c] = v[j];
+      }
+      if constexpr (NR > NS) {
+#pragma unroll
+        for (int j = 0; j < W; j++) E::derive(s[j]);
       }
     } else {
 #pragma unroll

@@ -52,6 +52,21 @@ int main(int argc, char** argv) {
       }
     }
   std::printf("sincos_bounded: %llu results, mismatches %llu\n", nb, bad_b);
+  // ---- sincos_reduced: binary64 accuracy itself, |x| <= 16, against libm
+  double worst = 0.0;
+  for (uint32_t sign = 0; sign < 2; sign++)
+    for (uint32_t b = 0; b <= hi16; b += stride * 5 + 3) {
+      const double x = (double)from_bits(b | (sign << 31)) * 1.0000000123;  // off the float grid
+      double s, c;
+      gx::math::sincos_reduced(x, s, c);
+      const double rs = std::sin(x), rc = std::cos(x);
+      // relative to the larger of |value| and 2^-20: next to a zero of sin or cos the reduction's
+      // absolute error (~1e-17) is what counts
+      const double es = std::fabs(s - rs) / std::fmax(std::fabs(rs), 0x1.0p-20);
+      const double ec = std::fabs(c - rc) / std::fmax(std::fabs(rc), 0x1.0p-20);
+      worst = std::fmax(worst, std::fmax(es, ec));
+    }
+  std::printf("sincos_reduced: worst relative error %.3g\n", worst);
   // ---- division by 1.1f
   const float c11 = 1.0f + 0.1f;
   unsigned long long nd = 0, bad_d = 0;
@@ -66,6 +81,6 @@ int main(int argc, char** argv) {
     }
   std::printf("div_by_total_mass: %llu inputs, mismatches %llu\n", nd, bad_d);
   // one rounding-boundary event per ~2^28 trig calls is expected; the division must be exact
-  const bool ok = bad_d == 0 && bad_b * (1ull << 24) <= nb + (1ull << 24) && bad_s * (1ull << 24) <= n + (1ull << 24) && bad_c * (1ull << 24) <= n + (1ull << 24);
+  const bool ok = worst < 1e-15 && bad_d == 0 && bad_b * (1ull << 24) <= nb + (1ull << 24) && bad_s * (1ull << 24) <= n + (1ull << 24) && bad_c * (1ull << 24) <= n + (1ull << 24);
   return ok ? 0 : 1;
 }
