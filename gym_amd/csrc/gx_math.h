@@ -5,6 +5,7 @@
 
 #include <math.h>
 #include <stdint.h>
+#include <string.h>
 
 #if defined(__HIPCC__)
 #define GX_HD __host__ __device__ __forceinline__
@@ -14,6 +15,41 @@
 
 namespace gx {
 namespace math {
+
+GX_HD uint64_t f64_bits(double x) {
+  uint64_t b;
+  memcpy(&b, &x, 8);
+  return b;
+}
+GX_HD double f64_from_bits(uint64_t b) {
+  double x;
+  memcpy(&x, &b, 8);
+  return x;
+}
+
+// From sin and cos of the reduced argument to those of x = r + q pi/2: swap when q is odd,
+// then the signs.  Written on the bit patterns (mask selects and a sign-bit xor) so that no
+// comparison results have to be kept in scalar registers across the polynomial evaluations.
+// (x & mask) | (y & ~mask)
+GX_HD uint32_t bit_select(uint32_t mask, uint32_t x, uint32_t y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t d;
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(mask), "v"(x), "v"(y));
+  return d;
+#else
+  return (x & mask) | (y & ~mask);
+#endif
+}
+GX_HD void quadrant(int q, double sn, double cs, double& s, double& c) {
+  const uint32_t odd = 0u - ((uint32_t)q & 1u);
+  const uint64_t bs = f64_bits(sn), bc = f64_bits(cs);
+  const uint32_t sl = (uint32_t)bs, sh = (uint32_t)(bs >> 32), cl = (uint32_t)bc, ch = (uint32_t)(bc >> 32);
+  const uint32_t al = bit_select(odd, cl, sl), ah = bit_select(odd, ch, sh);
+  const uint32_t bl = bit_select(odd, sl, cl), bh = bit_select(odd, sh, ch);
+  const uint32_t sign_s = ((uint32_t)q & 2u) << 30, sign_c = (((uint32_t)q + 1u) & 2u) << 30;
+  s = f64_from_bits(((uint64_t)(ah ^ sign_s) << 32) | al);
+  c = f64_from_bits(((uint64_t)(bh ^ sign_c) << 32) | bl);
+}
 
 // sin(x) and cos(x) in binary64 for |x| <= pi/4, no argument reduction.
 // Minimax kernels of the classic fdlibm form (sin: x + x^3 S(x^2), cos:
@@ -79,11 +115,7 @@ GX_HD void sincos_bounded(double x, double& s, double& c) {
   const double hz = 0.5 * z;
   const double w = 1.0 - hz;
   const double cs = w + (((1.0 - w) - hz) + fma(z * z, rc, -(r * t)));
-  const int q = (int)fn & 3;
-  const double a = (q & 1) ? cs : sn;
-  const double b = (q & 1) ? sn : cs;
-  s = (q & 2) ? -a : a;
-  c = ((q + 1) & 2) ? -b : b;
+  quadrant((int)fn, sn, cs, s, c);
 }
 
 // sin(x) and cos(x) in binary64 to a few units in the last place, for |x| up to
@@ -98,11 +130,7 @@ GX_HD void sincos_reduced(double x, double& s, double& c) {
   const double r = fma(-fn, P2, fma(-fn, P1, x));
   double sn, cs;
   sincos_small(r, sn, cs);
-  const int q = (int)fn & 3;
-  const double a = (q & 1) ? cs : sn;
-  const double b = (q & 1) ? sn : cs;
-  s = (q & 2) ? -a : a;
-  c = ((q + 1) & 2) ? -b : b;
+  quadrant((int)fn, sn, cs, s, c);
 }
 
 // x / 1.1f in binary32, correctly rounded, without a hardware divide: with
