@@ -37,10 +37,13 @@ FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X vector FP64 peak
 # statistics fused: each logical array counted once per read and once per
 # write at its stored width
 B_ALG = {
-    # state r+w, action r, steps r+w, ep_return r+w, reward w, done w
-    "cartpole": 16 + 16 + 4 + 4 + 4 + 4 + 4 + 4 + 1,       # 57
-    "mountaincar": 8 + 8 + 4 + 4 + 4 + 4 + 4 + 4 + 1,      # 41
-    "acrobot": 24 + 24 + 4 + 4 + 4 + 4 + 4 + 4 + 1,        # 73
+    # state r+w, action r, steps r+w, reward w, done w.  CartPole, MountainCar and Acrobot pay a
+    # constant reward on every non-final step, so with auto-reset the open-episode return is that
+    # constant times the step counter and no ep_return row is read or written
+    "cartpole": 16 + 16 + 4 + 4 + 4 + 4 + 1,               # 49
+    "mountaincar": 8 + 8 + 4 + 4 + 4 + 4 + 1,              # 33
+    "acrobot": 24 + 24 + 4 + 4 + 4 + 4 + 1,                # 65
+    # the others also read and write ep_return
     "pendulum": 12 + 12 + 4 + 4 + 4 + 8 + 8 + 8 + 1,       # 61: reward and ep_return are binary64
     "frozenlake": 4 + 4 + 4 + 4 + 4 + 4 + 4 + 4 + 1,       # 33
     "pong": 60 + 60 + 4 + 4 + 4 + 4 + 1 + 100800,          # 100937
@@ -185,8 +188,8 @@ def main():
     value = total_steps / wall
 
     if args.rk4:
-        # f64 state r+w, steps r+w, ep_return r+w, reward, done, derived f32 observation rows
-        b_alg = 32 + 32 + 4 + 4 + 4 + 4 + 4 + 1 + 24
+        # f64 state r+w, steps r+w, reward, done, derived f32 observation rows
+        b_alg = 32 + 32 + 4 + 4 + 4 + 1 + 24
     else:
         b_alg = B_ALG[args.env] - (4 if args.policy == "random" else 0)
     achieved = b_alg * n / (kernel_ms * 1e-3) / 1e9

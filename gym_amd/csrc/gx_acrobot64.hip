@@ -39,6 +39,7 @@ struct Acrobot64 {
   // the angles are wrapped to [-pi, pi] and the velocities bounded after every step, so
   // every sin/cos argument of an RK4 stage stays below 16 for any finite state
   static constexpr bool kAlwaysBounded = true;
+  static constexpr int kStepReturn = -1;  // reward -1 on every step but the final one
 
   static __device__ __forceinline__ void derive(double (&s)[NR]) {
     math::sincos_reduced(s[0], s[4], s[5]);

@@ -40,6 +40,8 @@ struct CartPole {
   // theta is unbounded when the pole keeps falling without a reset; with auto-reset every
   // stored theta is within the 12-degree threshold (Envs.CartPole.cs:45,70) or a fresh draw
   static constexpr bool kAlwaysBounded = false;
+  // reward 1 on every step but the final one (Envs.CartPole.cs:72)
+  static constexpr int kStepReturn = 1;
 
   // Envs.CartPole.cs:22-32
   static __device__ __forceinline__ void reset(float (&s)[NS], const RngKey& key, uint64_t env) {
@@ -99,6 +101,8 @@ struct MountainCar {
   // the position has no upper clamp (Envs.MountainCar.cs:38-44): past the goal it only stops
   // growing when the env is reset
   static constexpr bool kAlwaysBounded = false;
+  // reward -1 on every step but the final one (Envs.MountainCar.cs:45)
+  static constexpr int kStepReturn = -1;
 
   // Envs.MountainCar.cs:22-30
   static __device__ __forceinline__ void reset(float (&s)[NS], const RngKey& key, uint64_t env) {
@@ -139,6 +143,8 @@ struct MountainCarContinuous {
   static constexpr bool kCheckAction = false;
   static __device__ __forceinline__ bool action_valid(Act) { return true; }
   static constexpr bool kAlwaysBounded = false;
+  // rewards vary from step to step
+  static constexpr int kStepReturn = kNoStepReturn;
 
   // Envs.MountainCarContinuous.cs:19-27
   static __device__ __forceinline__ void reset(float (&s)[NS], const RngKey& key, uint64_t env) {
@@ -182,6 +188,8 @@ struct Pendulum {
   // theta comes out of atan2 every step and the speed is clamped to 8 before it is
   // integrated (Envs.Pendulum.cs:40,46-47): every angle is below 4 for any finite state
   static constexpr bool kAlwaysBounded = true;
+  // rewards vary from step to step
+  static constexpr int kStepReturn = kNoStepReturn;
 
   // Envs.Pendulum.cs:19-28
   static __device__ __forceinline__ void reset(float (&s)[NS], const RngKey& key, uint64_t env) {
@@ -238,6 +246,8 @@ struct Acrobot {
   // both angles come out of atan2 every step and the velocities are clamped to 4pi / 9pi
   // before they are integrated (Envs.Acrobot.cs:47-48,71-74): every angle is below 15
   static constexpr bool kAlwaysBounded = true;
+  // reward -1 on every step but the final one (Envs.Acrobot.cs:88)
+  static constexpr int kStepReturn = -1;
 
   // Envs.Acrobot.cs:22-28
   static __device__ __forceinline__ void reset(float (&s)[NS], const RngKey& key, uint64_t env) {

@@ -131,6 +131,9 @@ struct ThreadStats<double> {
 };
 
 // ---------------------------------------------------------------- kernels ---
+// E::kStepReturn of an env whose rewards differ from step to step
+constexpr int kNoStepReturn = 0x7FFFFFFF;
+
 // An env may keep derived quantities next to its stored state while it is in registers: E::NR
 // (>= E::NS) values per env, of which the first NS are the rows in memory and the rest are
 // recomputed by E::derive() after a load (E::reset() fills them itself).
@@ -165,6 +168,10 @@ __global__ void __launch_bounds__(kBlock, (FUSED && BOUNDED) ? GX_FUSED_MIN_WAVE
   uint8_t* const truncated_row = FUSED ? nullptr : a.truncated;
   Real* const sreal = static_cast<Real*>(a.state_real);
   int32_t* const steps_row = a.state_int;  // these envs have one int row: the step counter
+  // With auto-reset the return of the open episode of an env that pays a constant integer reward
+  // on every non-final step is that constant times the step counter: the row is neither read
+  // nor written (8 bytes per env-step less), the statistics come out the same.
+  const bool derive_returns = FUSED && E::kStepReturn != kNoStepReturn && a.derive_returns != 0;
   ThreadStats<EpRet> acc;
 
   const uint64_t ngroups = (a.num_envs + (W - 1)) / W;
@@ -189,7 +196,12 @@ __global__ void __launch_bounds__(kBlock, (FUSED && BOUNDED) ? GX_FUSED_MIN_WAVE
     }
     load_row<int32_t, W>(steps_row, q, steps);
     if (record) {
-      load_row<EpRet, W>(static_cast<const EpRet*>(a.ep_return), q, ep_ret);
+      if (derive_returns) {
+#pragma unroll
+        for (int j = 0; j < W; j++) ep_ret[j] = (EpRet)(E::kStepReturn * steps[j]);
+      } else {
+        load_row<EpRet, W>(static_cast<const EpRet*>(a.ep_return), q, ep_ret);
+      }
       if (ep_length_row) load_row<int32_t, W>(ep_length_row, q, ep_len);
     }
 
@@ -256,7 +268,7 @@ __global__ void __launch_bounds__(kBlock, (FUSED && BOUNDED) ? GX_FUSED_MIN_WAVE
     }
     store_row<int32_t, W>(steps_row, q, steps);
     if (record) {
-      store_row<EpRet, W>(static_cast<EpRet*>(a.ep_return), q, ep_ret);
+      if (!derive_returns) store_row<EpRet, W>(static_cast<EpRet*>(a.ep_return), q, ep_ret);
       if (ep_length_row) store_row<int32_t, W>(ep_length_row, q, ep_len);
     }
     // write-only rows: streamed past the caches, which stay with the rows the next step re-reads

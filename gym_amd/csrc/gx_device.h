@@ -204,6 +204,10 @@ struct StepArgs {
   int32_t table_states, table_actions, table_outcomes;
   int32_t start_state;
   int32_t step_limit;
+  // 1: the open-episode return is not stored; it is ret_per_step x the step counter (envs whose
+  // every non-final step pays the same integer reward, with auto-reset on)
+  int32_t derive_returns;
+  int32_t ret_per_step;
 };
 
 }  // namespace gx

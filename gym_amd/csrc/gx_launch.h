@@ -41,6 +41,7 @@ hipError_t launch_breakout_sample(const StepArgs& a, void* out, dim3 grid, hipSt
 hipError_t launch_stats_reduce(const StatSlot* slots, int num_slots, StatSlot* out, hipStream_t stream);
 hipError_t launch_stats_init(StatSlot* slots, int num_slots, hipStream_t stream);
 // EnvWrapper.cs:34-38: Reset() with an open episode records it first
+hipError_t launch_stats_materialize_returns(const StepArgs& a, const int32_t* length_row, dim3 grid, hipStream_t stream);
 hipError_t launch_stats_flush_open(const StepArgs& a, int ep_return_is_f64, const int32_t* length_row, dim3 grid,
                                    hipStream_t stream);
 

@@ -54,11 +54,24 @@ __global__ void __launch_bounds__(kBlock) stats_flush_open_kernel(StepArgs a, co
   EpRet* ep_ret = static_cast<EpRet*>(a.ep_return);
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < a.num_envs; i += (uint64_t)gridDim.x * kBlock) {
     const int len = length_row[i];
-    if (len > 0) acc.add((double)ep_ret[i], len);
+    if (len > 0) acc.add(a.derive_returns ? (double)(a.ret_per_step * len) : (double)ep_ret[i], len);
     ep_ret[i] = 0;
     if (a.ep_length) a.ep_length[i] = 0;
   }
   block_commit_stats(acc, a.stat_slots);
+}
+
+// Writes the derived returns (ret_per_step x step counter) into the ep_return row, for a batch
+// that stops deriving them (its state is about to be replaced from outside).
+__global__ void __launch_bounds__(kBlock) stats_materialize_returns_kernel(StepArgs a, const int32_t* length_row) {
+  int32_t* ep_ret = static_cast<int32_t*>(a.ep_return);
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < a.num_envs; i += (uint64_t)gridDim.x * kBlock)
+    ep_ret[i] = a.ret_per_step * length_row[i];
+}
+
+hipError_t launch_stats_materialize_returns(const StepArgs& a, const int32_t* length_row, dim3 grid, hipStream_t stream) {
+  hipLaunchKernelGGL(stats_materialize_returns_kernel, grid, dim3(kBlock), 0, stream, a, length_row);
+  return hipGetLastError();
 }
 
 hipError_t launch_stats_init(StatSlot* slots, int num_slots, hipStream_t stream) {

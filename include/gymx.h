@@ -173,7 +173,9 @@ int gx_vec_info(const gx_vec* vec, gx_info* out);
 int gx_vec_reset(gx_vec* vec);
 
 /* The reference keeps state private and has no setter; these exist for the
- * replay harness and double as checkpoint/resume.  Synchronous.
+ * replay harness and double as checkpoint/resume.  Synchronous.  The step
+ * counter of the image is also TimeLimit's counter and, with GX_AUTORESET, the
+ * length of the open episode; the return collected so far is kept.
  * Components of the SoA image (reals | ints), named after the reference's fields:
  *   CartPole   x, xDot, theta, thetaDot | steps          MountainCar(+Cont)  position, velocity | steps
  *   Pendulum   cos, sin, thetaDot | steps                Acrobot  cos1, sin1, cos2, sin2, thetaDot1, thetaDot2 | steps

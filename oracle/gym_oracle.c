@@ -1349,8 +1349,11 @@ void gxo_vec_set_state(gxo_vec* v, const void* buf) {
       memcpy((char*)tmp + (size_t)k * rsz, reals + ((size_t)k * v->n + i) * rsz, rsz);
     for (int k = 0; k < v->n_int; k++) itmp[k] = ints[(size_t)k * v->n + i];
     v->envs[i]->vt->import_state(v->envs[i], tmp, itmp);
-    /* the TimeLimit counter equals the env's own step counter at all times */
+    /* the TimeLimit counter equals the env's own step counter at all times, and so does the
+     * length of the open episode when every done step resets the env; the return collected
+     * so far is kept */
     v->tl_steps[i] = itmp[v->n_int - 1];
+    if (v->flags & GXO_AUTORESET) v->cur_length[i] = itmp[v->n_int - 1];
   }
 }
 
