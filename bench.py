@@ -43,9 +43,9 @@ B_ALG = {
     "cartpole": 16 + 16 + 4 + 4 + 4 + 4 + 1,               # 49
     "mountaincar": 8 + 8 + 4 + 4 + 4 + 4 + 1,              # 33
     "acrobot": 24 + 24 + 4 + 4 + 4 + 4 + 1,                # 65
+    "frozenlake": 4 + 4 + 4 + 4 + 4 + 4 + 1,               # 25 (every non-terminal move pays 0)
     # the others also read and write ep_return
     "pendulum": 12 + 12 + 4 + 4 + 4 + 8 + 8 + 8 + 1,       # 61: reward and ep_return are binary64
-    "frozenlake": 4 + 4 + 4 + 4 + 4 + 4 + 4 + 4 + 1,       # 33
     "pong": 60 + 60 + 4 + 4 + 4 + 4 + 1 + 100800,          # 100937
     "breakout": 72 + 72 + 4 + 4 + 4 + 4 + 1 + 100800,      # 100961
 }

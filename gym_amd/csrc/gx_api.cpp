@@ -314,6 +314,23 @@ int build_table(gx_vec* v, std::vector<uint32_t>& tab) {
     return GX_OK;
   }
   std::memcpy(&tab[tab.size() - 8], lut, sizeof lut);
+  // Does every non-terminal transition pay the same integer reward?  Then, with auto-reset on,
+  // the open-episode return is that reward times the step counter (see derive_returns).
+  {
+    bool constant = true, seen = false;
+    float c = 0.0f;
+    for (size_t i = 0; i + 8 < tab.size(); i++) {
+      if (tab[i] & kTerminalBit) continue;
+      const float r = lut[(tab[i] >> 16) & 0x7u];
+      if (!seen) { c = r; seen = true; }
+      else if (r != c) constant = false;
+    }
+    const uint32_t both = GX_AUTORESET | GX_RECORD_STATS;
+    if (seen && constant && c == (float)(int)c && (v->desc.flags & both) == both) {
+      v->derive_returns = true;
+      v->ret_per_step = (int)c;
+    }
+  }
   return GX_OK;
 }
 
@@ -559,7 +576,7 @@ extern "C" int gx_vec_create(gx_ctx* ctx, const gx_desc* desc, gx_vec** out) {
     }
     v->grid = dim3((unsigned)std::max<uint64_t>(1, std::min(blocks, cap)));
   }
-  {
+  if (v->is_classic) {
     const uint32_t both = GX_AUTORESET | GX_RECORD_STATS;
     const bool constant_reward = env == GX_ENV_CARTPOLE || env == GX_ENV_MOUNTAINCAR || env == GX_ENV_ACROBOT;
     v->derive_returns = constant_reward && (desc->flags & both) == both && desc->time_limit == 0;

@@ -62,6 +62,9 @@ __global__ void __launch_bounds__(kBlock) tabular_step_kernel(StepArgs a) {
 
   const bool autoreset = (a.flags & GX_AUTORESET) != 0;
   const bool record = (a.flags & GX_RECORD_STATS) != 0;
+  // every non-terminal transition of the table pays the same reward and auto-reset is on: the
+  // open-episode return is that reward times the step counter, its row is not touched
+  const bool derive_returns = a.derive_returns != 0;
   int32_t* const state_row = a.state_int;
   int32_t* const steps_row = a.state_int + a.stride;
   StatAcc acc;
@@ -74,7 +77,12 @@ __global__ void __launch_bounds__(kBlock) tabular_step_kernel(StepArgs a) {
     load4i(state_row, q, st);
     load4i(steps_row, q, steps);
     if (record) {
-      load4i(static_cast<const int32_t*>(a.ep_return), q, ep_ret);
+      if (derive_returns) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) ep_ret[j] = a.ret_per_step * steps[j];
+      } else {
+        load4i(static_cast<const int32_t*>(a.ep_return), q, ep_ret);
+      }
       if (a.ep_length) load4i(a.ep_length, q, ep_len);
     }
     float reward[4];
@@ -120,7 +128,7 @@ __global__ void __launch_bounds__(kBlock) tabular_step_kernel(StepArgs a) {
     store4i(state_row, q, st);
     store4i(steps_row, q, steps);
     if (record) {
-      store4i(static_cast<int32_t*>(a.ep_return), q, ep_ret);
+      if (!derive_returns) store4i(static_cast<int32_t*>(a.ep_return), q, ep_ret);
       if (a.ep_length) store4i(a.ep_length, q, ep_len);
     }
     // write-only rows stream past the caches

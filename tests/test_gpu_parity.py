@@ -322,7 +322,7 @@ def test_random_policy_and_rollout(oracle, env_id):
             assert np.array_equal(gi, oi) and s1.episodes == so.episodes and s1.sum_length == so.sum_length
 
 
-@pytest.mark.parametrize("env_id", [L.ENV_CARTPOLE, L.ENV_MOUNTAINCAR, L.ENV_ACROBOT])
+@pytest.mark.parametrize("env_id", [L.ENV_CARTPOLE, L.ENV_MOUNTAINCAR, L.ENV_ACROBOT, L.ENV_FROZENLAKE, L.ENV_CLIFFWALKING, L.ENV_TAXI])
 def test_fused_statistics_survive_set_state(oracle, env_id):
     """auto-reset + statistics on a constant-reward env: the open-episode return is implied by the step
     counter until the caller replaces the state (arbitrary counters), then it is tracked explicitly"""
@@ -337,7 +337,8 @@ def test_fused_statistics_survive_set_state(oracle, env_id):
         if t in (30, 60):
             reals, ints = o.get_state()
             ints = ints.copy()
-            ints[-1] = rng.integers(0, 480, n)  # any step counters, unrelated to the episodes' true lengths
+            # any step counters, unrelated to the episodes' true lengths
+            ints[-1] = rng.integers(0, 90 if env_id in TABULAR else 480, n)
             g.set_state(reals, ints); o.set_state(reals, ints)
         if t == 75:
             g.reset(); o.reset()
