@@ -110,6 +110,40 @@ def cpu_baseline(env_name, target_seconds=12.0):
     }
 
 
+def cpu_baseline_all_cores(env_name, target_seconds=5.0):
+    """The same env code on every host core this job may use (at most 16): contiguous env
+    structs, no result lists, one thread per core.  FrozenLake shares a map object and is skipped."""
+    from oracle import oracle as O
+
+    if env_name == "frozenlake":
+        return None
+    eid = {"cartpole": O.CARTPOLE, "acrobot": O.ACROBOT, "mountaincar": O.MOUNTAINCAR, "pendulum": O.PENDULUM,
+           "pong": O.PONG, "breakout": O.BREAKOUT}[env_name]
+    cores = max(1, min(16, len(os.sched_getaffinity(0))))
+    n = 1 << 18
+    secs, steps_done = O.bench_flat_threads(eid, n, 4, cores)
+    k = max(4, int(target_seconds * steps_done / max(secs, 1e-9) / n))
+    secs, steps_done = O.bench_flat_threads(eid, n, k, cores)
+    return {"value": steps_done / secs, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "%s game/dynamics step only (no frame rendering), %d envs x %d batched steps, random actions, reset on "
+                      "done; contiguous env structs, no result lists, %d threads" % (env_name, n, k, cores)}
+
+
+def d2d_copy_rate(nbytes=1 << 31, reps=5):
+    """Measured device-to-device copy rate (bytes read + bytes written per second), GB/s"""
+    src = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -173,7 +207,12 @@ def main():
     stream_ptr = torch.cuda.current_stream().cuda_stream
     view = batch.view()
     if k_roll > 1:
-        step_fn = lambda: batch.rollout(k_roll, L.POLICY_RANDOM, None, stream_ptr)  # noqa: E731
+        def step_fn():
+            # one fused rollout, then the episode statistics reduced on the device and across ranks
+            batch.rollout(k_roll, L.POLICY_RANDOM, None, stream_ptr)
+            if dist is not None:
+                torch.cuda.current_stream().synchronize()
+                allreduce_stats(batch.stats(), dist, device=COLLECTIVE_DEVICE)
     elif args.policy == "device":
         adt = torch.float32 if batch.info.action_dtype == L.F32 else torch.int32
         actions = torch.empty(int(view.stride), dtype=adt, device="cuda")
@@ -247,6 +286,9 @@ def main():
         out["extra"] = extra_measurements(ctx, n, stream_ptr)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.env)
+        allc = cpu_baseline_all_cores(args.env)
+        if allc:
+            out["cpu_baseline_all_cores"] = allc
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
@@ -257,7 +299,7 @@ def main():
 def extra_measurements(ctx, n, stream_ptr):
     """Secondary numbers named by the headline metric: Acrobot single-step (reference dynamics)
     and the fused 64-step RK4/binary64 rollout (FP64 vector-ALU bound)."""
-    res = {}
+    res = {"hbm_copy_ceiling_GBps_measured": d2d_copy_rate()}
     flags = L.AUTORESET | L.RECORD_STATS
     b = DeviceBatch(ctx, L.ENV_ACROBOT, n, seed=1, flags=flags)
     b.reset()

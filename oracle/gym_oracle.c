@@ -23,6 +23,7 @@
 #include "gym_oracle.h"
 
 #include <math.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1472,5 +1473,89 @@ double gxo_bench_reference_shaped(int env_id, uint64_t num_envs, int steps, uint
   free(actions);
   free(screens);
   gxo_vec_destroy(v);
+  return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
+
+/* ======================================================================
+ * CPU baseline, all cores: the same env code without what the reference's
+ * VectorEnv loop adds -- env structs in one contiguous array per thread (no
+ * heap object per env), no per-call result list, `threads` POSIX threads each
+ * stepping its own slice for `steps` batched steps.  An upper bound on what
+ * the host could do with this arithmetic, reported next to the 1-core figure.
+ * ====================================================================== */
+typedef struct soa_job {
+  const env_vtbl* vt;
+  char* envs;         /* count structs of vt->size bytes */
+  const char* actions;
+  uint64_t first, count, seed;
+  int steps;
+  double acc;
+} soa_job;
+
+static void* soa_worker(void* p) {
+  soa_job* j = (soa_job*)p;
+  double acc = 0.0;
+  for (int s = 0; s < j->steps; s++) {
+    for (uint64_t i = 0; i < j->count; i++) {
+      env_obj* e = (env_obj*)(j->envs + i * j->vt->size);
+      rng_ctx r = {j->seed, j->first + i, (uint64_t)s + 1};
+      double reward;
+      int done;
+      j->vt->step(e, j->actions + (j->first + i) * 4, &r, &reward, &done);
+      acc += reward;
+      if (done) j->vt->reset(e, &r);
+    }
+  }
+  j->acc = acc;
+  return NULL;
+}
+
+double gxo_bench_flat_threads(int env_id, uint64_t num_envs, int steps, int threads, uint64_t seed, uint64_t* env_steps,
+                              double* checksum) {
+  gxo_vec* v = gxo_vec_create(env_id, threads > 0 ? (uint64_t)threads : 1, seed, 0, 0, NULL, 0);
+  if (!v || threads <= 0 || v->grid) { /* grid envs share a map object; not needed for the baseline */
+    gxo_vec_destroy(v);
+    return -1.0;
+  }
+  const env_vtbl* vt = v->envs[0]->vt;
+  static const int nact[GXO_NUM_ENVS] = {2, 3, 0, 0, 3, 4, 6, 4, 4, 3, 4};
+  char* actions = (char*)malloc(num_envs * 4);
+  for (uint64_t i = 0; i < num_envs; i++) {
+    if (v->action_is_float) {
+      float lim = env_id == GXO_PENDULUM ? 2.0f : 1.0f;
+      ((float*)actions)[i] = gxo_box_sample(gxo_rng_uniform(seed, i, 0, 2, 0), -lim, lim);
+    } else {
+      ((int32_t*)actions)[i] = gxo_rng_below(seed, i, 0, 2, 0, nact[env_id]);
+    }
+  }
+  soa_job* jobs = (soa_job*)calloc((size_t)threads, sizeof *jobs);
+  pthread_t* tid = (pthread_t*)calloc((size_t)threads, sizeof *tid);
+  uint64_t per = (num_envs + (uint64_t)threads - 1) / (uint64_t)threads;
+  for (int t = 0; t < threads; t++) {
+    uint64_t first = (uint64_t)t * per, count = first >= num_envs ? 0 : (num_envs - first < per ? num_envs - first : per);
+    jobs[t].vt = vt; jobs[t].first = first; jobs[t].count = count; jobs[t].seed = seed; jobs[t].steps = steps;
+    jobs[t].actions = actions;
+    jobs[t].envs = (char*)calloc(count ? count : 1, vt->size);
+    for (uint64_t i = 0; i < count; i++) {
+      env_obj* e = (env_obj*)(jobs[t].envs + i * vt->size);
+      memcpy(e, v->envs[0], vt->size); /* vtable pointer and constructor state */
+      rng_ctx r = {seed, first + i, 0};
+      vt->reset(e, &r);
+    }
+  }
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (int t = 0; t < threads; t++) pthread_create(&tid[t], NULL, soa_worker, &jobs[t]);
+  double acc = 0.0;
+  for (int t = 0; t < threads; t++) {
+    pthread_join(tid[t], NULL);
+    acc += jobs[t].acc;
+  }
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  for (int t = 0; t < threads; t++) free(jobs[t].envs);
+  free(jobs); free(tid); free(actions);
+  gxo_vec_destroy(v);
+  if (env_steps) *env_steps = num_envs * (uint64_t)steps;
+  if (checksum) *checksum = acc;
   return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }

@@ -124,6 +124,10 @@ void gxo_breakout_render(double ball_x, double ball_y, double paddle_x, int ball
 double gxo_bench_reference_shaped(int env_id, uint64_t num_envs, int steps, uint64_t seed,
                                   uint64_t* env_steps, double* checksum);
 
+/* ---- CPU baseline on `threads` cores: contiguous env structs, no result lists. */
+double gxo_bench_flat_threads(int env_id, uint64_t num_envs, int steps, int threads, uint64_t seed,
+                              uint64_t* env_steps, double* checksum);
+
 #ifdef __cplusplus
 }
 #endif

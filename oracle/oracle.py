@@ -90,6 +90,8 @@ def lib():
     L.gxo_breakout_render.argtypes = [dbl, dbl, dbl, C.c_int, C.c_int, C.c_int, vp, vp]
     L.gxo_bench_reference_shaped.restype = dbl
     L.gxo_bench_reference_shaped.argtypes = [C.c_int, u64, C.c_int, u64, C.POINTER(u64), C.POINTER(dbl)]
+    L.gxo_bench_flat_threads.restype = dbl
+    L.gxo_bench_flat_threads.argtypes = [C.c_int, u64, C.c_int, C.c_int, u64, C.POINTER(u64), C.POINTER(dbl)]
     _lib = L
     return L
 
@@ -235,6 +237,13 @@ def breakout_render(ball_x, ball_y, paddle_x, ball_stuck, score, lives, bricks):
     assert w.shape == (4,)
     lib().gxo_breakout_render(ball_x, ball_y, paddle_x, int(ball_stuck), score, lives, _ptr(w), _ptr(out))
     return out
+
+
+def bench_flat_threads(env_id, num_envs, steps, threads, seed=0):
+    n = C.c_uint64()
+    chk = C.c_double()
+    secs = lib().gxo_bench_flat_threads(env_id, num_envs, steps, threads, seed, C.byref(n), C.byref(chk))
+    return secs, n.value
 
 
 def bench_reference_shaped(env_id, num_envs, steps, seed=0):
