@@ -2,13 +2,19 @@
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def run(args):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "50", "--warmup", "5", "--no-cpu-baseline", "--no-extra"] + args, capture_output=True, text=True)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "200", "--warmup", "20", "--no-cpu-baseline", "--no-extra"] + args, capture_output=True, text=True)
     try:
         j = json.loads(r.stdout.strip().splitlines()[-1])
-        return "%.4f ms  %.3e steps/s  %.0f GB/s (%.1f%% of 8 TB/s)" % (j["roofline"]["kernel_ms"], j["value"], j["roofline"]["achieved"], 100 * j["roofline"]["frac"])
+        return "%.4f ms  %.3e steps/s  %.0f %s (%.1f%% of peak), %d B/env-step" % (
+            j["roofline"]["kernel_ms"], j["value"], j["roofline"]["achieved"], j["roofline"]["unit"], 100 * j["roofline"]["frac"],
+            j["roofline"].get("bytes_per_env_step", 0))
     except Exception:
         return r.stderr[-300:]
-for env, n in [("cartpole", 1 << 24), ("mountaincar", 1 << 24), ("pendulum", 1 << 24), ("acrobot", 1 << 24), ("frozenlake", 1 << 26), ("pong", 65536)]:
+for env, n in [("cartpole", 1 << 24), ("mountaincar", 1 << 24), ("pendulum", 1 << 24), ("acrobot", 1 << 24), ("frozenlake", 1 << 26), ("pong", 65536), ("breakout", 65536)]:
     for pol in ("device", "random"):
         print(env, n, pol, run(["--env", env, "--num-envs", str(n), "--policy", pol]), flush=True)
 print("cartpole fast32", run(["--mode", "fast32"]), flush=True)
+print("acrobot fast32", run(["--env", "acrobot", "--mode", "fast32", "--policy", "random"]), flush=True)
+print("acrobot rk4 single step", run(["--env", "acrobot", "--rk4", "--policy", "random"]), flush=True)
+print("acrobot rk4 rollout 64", run(["--env", "acrobot", "--rk4", "--rollout", "64", "--steps", "5", "--warmup", "1"]), flush=True)
+print("cartpole rollout 64", run(["--env", "cartpole", "--rollout", "64", "--steps", "5", "--warmup", "1"]), flush=True)
