@@ -14,7 +14,7 @@ public enum GxStatus { Ok = 0, Invalid = 1, Hip = 2, Oom = 3, Unsupported = 4, R
 public enum GxEnvId
 {
     CartPole = 0, MountainCar = 1, MountainCarContinuous = 2, Pendulum = 3, Acrobot = 4,
-    FrozenLake = 5, Taxi = 6, CliffWalking = 7, Pong = 8, Dummy = 9, Breakout = 10
+    FrozenLake = 5, Taxi = 6, CliffWalking = 7, Pong = 8, Dummy = 9, Breakout = 10, SpaceInvaders = 11
 }
 
 public enum GxMode { Exact = 0, Fast32 = 1 }

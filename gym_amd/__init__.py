@@ -4,12 +4,12 @@ from . import spaces
 from .env import (ActionWrapper, Env, EnvWrapper, ObservationWrapper, RecordEpisodeStatistics, RewardWrapper,
                   TimeLimit)
 from .envs import (Acrobot, Breakout, CartPole, CliffWalking, DummyEnv, FrozenLake, MountainCar,
-                   MountainCarContinuous, Pendulum, Pong, Taxi)
+                   MountainCarContinuous, Pendulum, Pong, SpaceInvaders, Taxi)
 from .registry import EnvRegistry, RegisterAll
 from .spaces import Box, Discrete
 from .vector_env import VectorEnv
 
 __all__ = ["spaces", "Env", "EnvWrapper", "ObservationWrapper", "ActionWrapper", "RewardWrapper",
            "RecordEpisodeStatistics", "TimeLimit", "CartPole", "MountainCar", "MountainCarContinuous", "Pendulum",
-           "Acrobot", "FrozenLake", "Taxi", "CliffWalking", "Pong", "Breakout", "DummyEnv", "EnvRegistry", "RegisterAll",
+           "Acrobot", "FrozenLake", "Taxi", "CliffWalking", "Pong", "Breakout", "SpaceInvaders", "DummyEnv", "EnvRegistry", "RegisterAll",
            "Box", "Discrete", "VectorEnv"]

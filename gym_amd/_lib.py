@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("GYMX_LIB") or os.path.join(_HERE, "lib", "libgymx.so"
 GX_OK, GX_ERR_INVALID, GX_ERR_HIP, GX_ERR_OOM, GX_ERR_UNSUPPORTED, GX_ERR_RCCL = range(6)
 
 (ENV_CARTPOLE, ENV_MOUNTAINCAR, ENV_MOUNTAINCAR_CONT, ENV_PENDULUM, ENV_ACROBOT, ENV_FROZENLAKE, ENV_TAXI,
- ENV_CLIFFWALKING, ENV_PONG, ENV_DUMMY, ENV_BREAKOUT) = range(11)
+ ENV_CLIFFWALKING, ENV_PONG, ENV_DUMMY, ENV_BREAKOUT, ENV_SPACEINVADERS) = range(12)
 MODE_EXACT, MODE_FAST32 = 0, 1
 AUTORESET, RECORD_STATS, SLIPPERY, TAXI_FULL, ACROBOT_RK4 = 1, 2, 4, 8, 16
 POLICY_DEVICE_ACTIONS, POLICY_RANDOM = 0, 1

@@ -59,7 +59,7 @@ struct gx_vec {
   std::string map;
   uint64_t n = 0, stride = 0, tick = 0;
   int envs_per_lane = 4;
-  bool is_classic = false, is_tabular = false, is_frame = false, is_acrobot64 = false;  // is_frame: Pong, Breakout
+  bool is_classic = false, is_tabular = false, is_frame = false, is_acrobot64 = false;  // is_frame: Pong, Breakout, SpaceInvaders
   bool ep_return_f64 = false;
   // device memory
   void* d_real = nullptr;
@@ -373,6 +373,10 @@ void fill_info(gx_vec* v) {
       in.n_real = 5; in.real_dtype = GX_F64; in.n_int = 8; in.obs_dim = 210 * 160 * 3; in.obs_dtype = GX_U8;
       in.action_n = 4; in.obs_is_state = 0;
       break;
+    case GX_ENV_SPACEINVADERS:                                                                    // Envs.SpaceInvaders.cs:47-51
+      in.n_real = 13; in.real_dtype = GX_F64; in.n_int = 9; in.obs_dim = 210 * 160 * 3; in.obs_dtype = GX_U8;
+      in.action_n = 6; in.obs_is_state = 0;
+      break;
   }
   in.state_bytes = v->n * ((uint64_t)in.n_real * dtype_size(in.real_dtype) + (uint64_t)in.n_int * 4);
   in.obs_bytes = v->n * (uint64_t)in.obs_dim * dtype_size(in.obs_dtype);
@@ -380,13 +384,25 @@ void fill_info(gx_vec* v) {
 
 // the frame envs: game-state kernel, then the raster kernel over every env's frame
 hipError_t frame_step(const gx_vec* v, const StepArgs& a, int policy, hipStream_t stream) {
-  return v->desc.env_id == GX_ENV_PONG ? launch_pong_step(a, policy, v->grid, stream) : launch_breakout_step(a, policy, v->grid, stream);
+  switch (v->desc.env_id) {
+    case GX_ENV_PONG: return launch_pong_step(a, policy, v->grid, stream);
+    case GX_ENV_BREAKOUT: return launch_breakout_step(a, policy, v->grid, stream);
+    default: return launch_invaders_step(a, policy, v->grid, stream);
+  }
 }
 hipError_t frame_reset(const gx_vec* v, const StepArgs& a, hipStream_t stream) {
-  return v->desc.env_id == GX_ENV_PONG ? launch_pong_reset(a, v->grid, stream) : launch_breakout_reset(a, v->grid, stream);
+  switch (v->desc.env_id) {
+    case GX_ENV_PONG: return launch_pong_reset(a, v->grid, stream);
+    case GX_ENV_BREAKOUT: return launch_breakout_reset(a, v->grid, stream);
+    default: return launch_invaders_reset(a, v->grid, stream);
+  }
 }
 hipError_t frame_raster(const gx_vec* v, const StepArgs& a, hipStream_t stream) {
-  return v->desc.env_id == GX_ENV_PONG ? launch_pong_raster(a, v->d_frames, stream) : launch_breakout_raster(a, v->d_frames, stream);
+  switch (v->desc.env_id) {
+    case GX_ENV_PONG: return launch_pong_raster(a, v->d_frames, stream);
+    case GX_ENV_BREAKOUT: return launch_breakout_raster(a, v->d_frames, stream);
+    default: return launch_invaders_raster(a, v->d_frames, stream);
+  }
 }
 
 StepArgs make_args(const gx_vec* v, const void* d_actions, int k_steps, uint64_t action_stride) {
@@ -455,7 +471,8 @@ int launch_sample(gx_vec* v, uint64_t tick, void* d_out, hipStream_t stream) {
   else if (v->is_classic) e = launch_classic_sample(v->desc.env_id, a, d_out, grid, stream);
   else if (v->is_tabular) e = launch_tabular_sample(v->desc.env_id, a, d_out, grid, stream);
   else if (v->desc.env_id == GX_ENV_PONG) e = launch_pong_sample(a, d_out, grid, stream);
-  else e = launch_breakout_sample(a, d_out, grid, stream);
+  else if (v->desc.env_id == GX_ENV_BREAKOUT) e = launch_breakout_sample(a, d_out, grid, stream);
+  else e = launch_invaders_sample(a, d_out, grid, stream);
   if (e != hipSuccess) return fail(GX_ERR_HIP, "sample kernel launch failed: %s", hipGetErrorString(e));
   return GX_OK;
 }
@@ -514,7 +531,7 @@ extern "C" int gx_vec_create(gx_ctx* ctx, const gx_desc* desc, gx_vec** out) {
   v->is_acrobot64 = env == GX_ENV_ACROBOT && (desc->flags & GX_ACROBOT_RK4);
   v->is_classic = env <= GX_ENV_ACROBOT;
   v->is_tabular = env == GX_ENV_FROZENLAKE || env == GX_ENV_TAXI || env == GX_ENV_CLIFFWALKING || env == GX_ENV_DUMMY;
-  v->is_frame = env == GX_ENV_PONG || env == GX_ENV_BREAKOUT;
+  v->is_frame = env == GX_ENV_PONG || env == GX_ENV_BREAKOUT || env == GX_ENV_SPACEINVADERS;
   v->envs_per_lane = v->is_acrobot64 ? 2 : (v->is_frame ? 1 : 4);
   v->stride = (v->n + 3) & ~3ull;  // rows stay 16-byte aligned for every element width
   v->ep_return_f64 = env == GX_ENV_MOUNTAINCAR_CONT || env == GX_ENV_PENDULUM;
@@ -597,7 +614,8 @@ extern "C" int gx_vec_create(gx_ctx* ctx, const gx_desc* desc, gx_vec** out) {
     }
   }
   if (v->is_frame) {
-    // the Pong and Breakout constructors call Reset() (Envs.Pong.cs:47-52, Envs.Breakout.cs:54-60); tick stays 0
+    // the Pong, Breakout and SpaceInvaders constructors call Reset() (Envs.Pong.cs:47-52,
+    // Envs.Breakout.cs:54-60, Envs.SpaceInvaders.cs:59-67); tick stays 0
     StepArgs a = make_args(v, nullptr, 1, 0);
     VEC_TRY(frame_reset(v, a, ctx->compute));
     VEC_TRY(frame_raster(v, a, ctx->compute));

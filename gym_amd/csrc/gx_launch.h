@@ -37,6 +37,12 @@ hipError_t launch_breakout_reset(const StepArgs& a, dim3 grid, hipStream_t strea
 hipError_t launch_breakout_raster(const StepArgs& a, uint8_t* frames, hipStream_t stream);
 hipError_t launch_breakout_sample(const StepArgs& a, void* out, dim3 grid, hipStream_t stream);
 
+// SpaceInvaders (gx_invaders.hip)
+hipError_t launch_invaders_step(const StepArgs& a, int policy, dim3 grid, hipStream_t stream);
+hipError_t launch_invaders_reset(const StepArgs& a, dim3 grid, hipStream_t stream);
+hipError_t launch_invaders_raster(const StepArgs& a, uint8_t* frames, hipStream_t stream);
+hipError_t launch_invaders_sample(const StepArgs& a, void* out, dim3 grid, hipStream_t stream);
+
 // statistics (gx_stats.hip)
 hipError_t launch_stats_reduce(const StatSlot* slots, int num_slots, StatSlot* out, hipStream_t stream);
 hipError_t launch_stats_init(StatSlot* slots, int num_slots, hipStream_t stream);

@@ -252,6 +252,38 @@ class Breakout(DeviceEnv):
                 "ball_y": float(reals[1, index]), "bricks_remaining": sum(bin(int(w)).count("1") for w in words)}
 
 
+class SpaceInvaders(DeviceEnv):
+    """Envs.SpaceInvaders.cs:12-541: Env<byte[], int>; the observation is the 210x160x3 frame"""
+    ENV_ID, ID = L.ENV_SPACEINVADERS, "SpaceInvaders-v4"
+    FRAME = 210 * 160 * 3
+
+    def __init__(self, **kw):
+        super().__init__(**kw)
+        self.ActionSpace = Discrete(6)  # 0 NOOP, 1 FIRE, 2 RIGHT, 3 LEFT, 4 RIGHTFIRE, 5 LEFTFIRE
+        self.ObservationSpace = Box(np.zeros(self.FRAME, np.float32), np.full(self.FRAME, 255.0, np.float32))
+
+    @property
+    def Spec(self):
+        return {"id": "SpaceInvaders-v4", "max_episode_steps": 10000}  # Envs.SpaceInvaders.cs:53
+
+    @property
+    def Metadata(self):
+        return {"render_modes": ["human", "rgb_array"]}
+
+    @property
+    def RewardRange(self):
+        return (0, 200)
+
+    def _state_of(self, obs, index=0):
+        return np.array(obs[index], np.uint8)
+
+    def _info(self, batch, index=0):
+        reals, ints = batch.get_state()  # Envs.SpaceInvaders.cs:181-187
+        bits = (int(ints[6, index]) & 0xFFFFFFFF) | ((int(ints[7, index]) & 0xFFFFFFFF) << 32)
+        return {"score": int(ints[0, index]), "lives": int(ints[1, index]), "aliens_remaining": bin(bits).count("1"),
+                "player_x": float(reals[0, index])}
+
+
 class DummyEnv(_IntStateEnv):
     """DummyEnv.cs:10-38"""
     ENV_ID, ID = L.ENV_DUMMY, "Dummy"

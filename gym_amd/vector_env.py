@@ -113,7 +113,7 @@ class VectorEnv:
         states = self._states(obs)
         out = []
         for i in range(self._batch.n):
-            info = self._proto._info(self._batch, i) if self._proto.ENV_ID in (L.ENV_PONG, L.ENV_BREAKOUT) else {}
+            info = self._proto._info(self._batch, i) if self._proto.ENV_ID in (L.ENV_PONG, L.ENV_BREAKOUT, L.ENV_SPACEINVADERS) else {}
             if trunc is not None and trunc[i]:
                 info["TimeLimit.truncated"] = True  # Wrappers.TimeLimit.cs:30
             out.append((states[i], float(reward[i]), bool(done[i]), info))

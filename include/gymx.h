@@ -57,7 +57,8 @@ typedef enum gx_env_id {
   GX_ENV_PONG = 8,             /* "Pong-v4"                  Envs.Pong.cs */
   GX_ENV_DUMMY = 9,            /* DummyEnv.cs */
   GX_ENV_BREAKOUT = 10,        /* "Breakout-v4"              Envs.Breakout.cs */
-  GX_ENV_COUNT = 11
+  GX_ENV_SPACEINVADERS = 11,   /* "SpaceInvaders-v4"         Envs.SpaceInvaders.cs */
+  GX_ENV_COUNT = 12
 } gx_env_id;
 
 /* Numeric mode of the continuous-control kernels. */
@@ -116,7 +117,7 @@ typedef struct gx_info {
   int32_t real_dtype;      /* GX_F32 or GX_F64 */
   int32_t n_int;           /* int32 state components, the last is the step counter */
   int32_t obs_dim;         /* elements per env in the observation */
-  int32_t obs_dtype;       /* GX_F32 (classic control), GX_I32 (tabular), GX_U8 (Pong, Breakout) */
+  int32_t obs_dtype;       /* GX_F32 (classic control), GX_I32 (tabular), GX_U8 (Pong, Breakout, SpaceInvaders) */
   int32_t action_dtype;    /* GX_I32 (Discrete) or GX_F32 (Box of dimension 1) */
   int32_t action_n;        /* Discrete.N, or 0 for Box */
   float action_low, action_high; /* Box bounds when action_dtype == GX_F32 */
@@ -133,7 +134,7 @@ typedef struct gx_view {
   void* state_real;   /* [n_real][stride] float or double */
   int32_t* state_int; /* [n_int][stride] */
   void* obs;          /* classic: == state_real (or float [obs_dim][stride] when it is derived);
-                         tabular: == state_int; Pong, Breakout: uint8 [num_envs][100800] */
+                         tabular: == state_int; Pong, Breakout, SpaceInvaders: uint8 [num_envs][100800] */
   void* reward;       /* [num_envs] float or double (gx_info.reward_dtype) */
   uint8_t* done;      /* [num_envs] */
   uint8_t* truncated; /* [num_envs], NULL unless time_limit > 0 */
@@ -183,11 +184,16 @@ int gx_vec_reset(gx_vec* vec);
  *   tabular, Dummy   - | state, steps
  *   Pong (f64)     ballX, ballY, ballVelX, ballVelY, leftPaddleY, rightPaddleY | leftScore, rightScore, steps
  *   Breakout (f64) ballX, ballY, ballVelX, ballVelY, paddleX | score, lives, ballStuck,
- *                  bricks[0..3] (bit row*18+col of word (row*18+col)/32 set = brick present), steps */
+ *                  bricks[0..3] (bit row*18+col of word (row*18+col)/32 set = brick present), steps
+ *   SpaceInvaders (f64) playerX, alienFormationX, alienFormationY, playerBullets[0..2] (x, y),
+ *                  alienBullets[0..1] (x, y) | score, lives, frameCounter, alienMoveRight, playerBullets.Count,
+ *                  alienBullets.Count, aliens bits 0..31, aliens bits 32..54 (bit row*11+col), steps.
+ *                  The reference's alien bullet list is unbounded; a game never holds more than one
+ *                  (fired every 60 steps at most, gone within 40), the image holds two. */
 int gx_vec_get_state(gx_vec* vec, void* host_soa, size_t bytes);
 int gx_vec_set_state(gx_vec* vec, const void* host_soa, size_t bytes);
 /* Observation of every env as Reset()/Step() would return it: classic control
- * float[obs_dim][num_envs]; tabular int32[num_envs]; Pong and Breakout uint8[num_envs][100800].
+ * float[obs_dim][num_envs]; tabular int32[num_envs]; Pong, Breakout and SpaceInvaders uint8[num_envs][100800].
  * Synchronous. */
 int gx_vec_get_obs(gx_vec* vec, void* host_obs, size_t bytes);
 

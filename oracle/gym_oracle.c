@@ -1069,6 +1069,250 @@ static void breakout_import(env_obj* e, const void* reals, const int32_t* ints) 
 }
 static const env_vtbl breakout_vt = {breakout_reset, breakout_step, breakout_export, breakout_import, sizeof(breakout_t)};
 
+/* ----------------------------------------------------------- SpaceInvaders */
+#define SI_PLAYER_SPEED 3.0
+#define SI_BULLET_SPEED 6.0
+#define SI_ALIEN_SPEED 0.5
+#define SI_ALIEN_DROP_SPEED 8.0
+#define SI_PLAYER_WIDTH 8
+#define SI_PLAYER_HEIGHT 6
+#define SI_ALIEN_WIDTH 6
+#define SI_ALIEN_HEIGHT 6
+#define SI_BULLET_WIDTH 2
+#define SI_BULLET_HEIGHT 4
+#define SI_ALIEN_ROWS 5
+#define SI_ALIEN_COLS 11
+#define SI_MAX_PLAYER_BULLETS 3 /* Envs.SpaceInvaders.cs:195 */
+/* The reference's alien bullet list is unbounded, but a bullet is fired at most every 60 steps
+ * (:136) and leaves the screen within 40 (4.2 px per step from y >= 46), so a game never holds
+ * more than one; the state image has room for two and a third is dropped. */
+#define SI_MAX_ALIEN_BULLETS 2
+
+typedef struct {
+  env_obj base;
+  double playerX, formX, formY;
+  double pbx[SI_MAX_PLAYER_BULLETS], pby[SI_MAX_PLAYER_BULLETS];
+  double abx[SI_MAX_ALIEN_BULLETS], aby[SI_MAX_ALIEN_BULLETS];
+  int32_t score, lives, frameCounter, moveRight, npb, nab;
+  uint8_t aliens[SI_ALIEN_ROWS][SI_ALIEN_COLS];
+  int32_t steps;
+} invaders_t;
+
+/* Envs.SpaceInvaders.cs:69-96 (no random draw) */
+static void invaders_reset(env_obj* e, const rng_ctx* r) {
+  (void)r;
+  invaders_t* c = (invaders_t*)e;
+  for (int row = 0; row < SI_ALIEN_ROWS; row++)
+    for (int col = 0; col < SI_ALIEN_COLS; col++) c->aliens[row][col] = 1;
+  c->playerX = SCREEN_WIDTH / 2.0 - SI_PLAYER_WIDTH / 2.0;
+  c->formX = 10;
+  c->formY = 40;
+  c->moveRight = 1;
+  c->npb = 0;
+  c->nab = 0;
+  for (int i = 0; i < SI_MAX_PLAYER_BULLETS; i++) c->pbx[i] = c->pby[i] = 0;
+  for (int i = 0; i < SI_MAX_ALIEN_BULLETS; i++) c->abx[i] = c->aby[i] = 0;
+  c->score = 0;
+  c->lives = 3;
+  c->steps = 0;
+  c->frameCounter = 0;
+}
+
+/* List<T>.RemoveAt: later elements move down; the vacated slot reads 0 in the state image */
+static void si_remove(double* x, double* y, int32_t* n, int i) {
+  for (int k = i; k + 1 < *n; k++) { x[k] = x[k + 1]; y[k] = y[k + 1]; }
+  (*n)--;
+  x[*n] = 0; y[*n] = 0;
+}
+
+/* Envs.SpaceInvaders.cs:192-199 */
+static void si_fire_player(invaders_t* c) {
+  if (c->npb < SI_MAX_PLAYER_BULLETS) {
+    c->pbx[c->npb] = c->playerX + SI_PLAYER_WIDTH / 2.0;
+    c->pby[c->npb] = SCREEN_HEIGHT - 40;
+    c->npb++;
+  }
+}
+
+/* Envs.SpaceInvaders.cs:98-190 (game state only; the frame is drawn by gxo_invaders_render) */
+static int invaders_step(env_obj* e, const void* action, const rng_ctx* r, double* reward, int* done) {
+  invaders_t* c = (invaders_t*)e;
+  int a = *(const int32_t*)action;
+  c->steps++;
+  c->frameCounter++;
+  double rew = 0.0;
+  switch (a) {
+    case 1: si_fire_player(c); break;
+    case 2: c->playerX = dmin(SCREEN_WIDTH - SI_PLAYER_WIDTH, c->playerX + SI_PLAYER_SPEED); break;
+    case 3: c->playerX = dmax(0, c->playerX - SI_PLAYER_SPEED); break;
+    case 4:
+      c->playerX = dmin(SCREEN_WIDTH - SI_PLAYER_WIDTH, c->playerX + SI_PLAYER_SPEED);
+      si_fire_player(c);
+      break;
+    case 5:
+      c->playerX = dmax(0, c->playerX - SI_PLAYER_SPEED);
+      si_fire_player(c);
+      break;
+    default: break;
+  }
+  /* UpdateBullets, :226-257 */
+  for (int i = c->npb - 1; i >= 0; i--) {
+    c->pby[i] -= SI_BULLET_SPEED;
+    if (c->pby[i] < 0) si_remove(c->pbx, c->pby, &c->npb, i);
+  }
+  for (int i = c->nab - 1; i >= 0; i--) {
+    c->aby[i] += SI_BULLET_SPEED * 0.7;
+    if (c->aby[i] > SCREEN_HEIGHT) si_remove(c->abx, c->aby, &c->nab, i);
+  }
+  /* UpdateAliens every 10 frames, :259-279 */
+  if (c->frameCounter % 10 == 0) {
+    if (c->moveRight) {
+      c->formX += SI_ALIEN_SPEED;
+      if (c->formX + SI_ALIEN_COLS * 12 > SCREEN_WIDTH - 10) {
+        c->moveRight = 0;
+        c->formY += SI_ALIEN_DROP_SPEED;
+      }
+    } else {
+      c->formX -= SI_ALIEN_SPEED;
+      if (c->formX < 10) {
+        c->moveRight = 1;
+        c->formY += SI_ALIEN_DROP_SPEED;
+      }
+    }
+  }
+  /* alien shooting, :136-139 and :201-224: draw 0 decides, draw 1 picks the column (stream 1) */
+  if (c->frameCounter % 60 == 0 && gxo_rng_uniform(r->seed, r->env_index, r->tick, 1, 0) < 0.3) {
+    int srow[SI_ALIEN_COLS], scol[SI_ALIEN_COLS], ns = 0;
+    for (int col = 0; col < SI_ALIEN_COLS; col++)
+      for (int row = SI_ALIEN_ROWS - 1; row >= 0; row--)
+        if (c->aliens[row][col]) { srow[ns] = row; scol[ns] = col; ns++; break; }
+    if (ns > 0) {
+      int k = gxo_rng_below(r->seed, r->env_index, r->tick, 1, 1, ns);
+      if (c->nab < SI_MAX_ALIEN_BULLETS) {
+        c->abx[c->nab] = c->formX + scol[k] * 12 + SI_ALIEN_WIDTH / 2.0;
+        c->aby[c->nab] = c->formY + srow[k] * 10 + SI_ALIEN_HEIGHT;
+        c->nab++;
+      }
+    }
+  }
+  /* CheckCollisions, :281-339 */
+  for (int i = c->npb - 1; i >= 0; i--) {
+    double bx = c->pbx[i], by = c->pby[i];
+    int hit = 0;
+    for (int row = 0; row < SI_ALIEN_ROWS && !hit; row++)
+      for (int col = 0; col < SI_ALIEN_COLS && !hit; col++)
+        if (c->aliens[row][col]) {
+          double alienX = c->formX + col * 12, alienY = c->formY + row * 10;
+          if (bx >= alienX && bx <= alienX + SI_ALIEN_WIDTH && by >= alienY && by <= alienY + SI_ALIEN_HEIGHT) {
+            c->aliens[row][col] = 0;
+            si_remove(c->pbx, c->pby, &c->npb, i);
+            int points = row == 0 ? 30 : (row <= 2 ? 20 : 10);
+            c->score += points;
+            rew += points;
+            hit = 1;
+          }
+        }
+  }
+  for (int i = c->nab - 1; i >= 0; i--) {
+    double bx = c->abx[i], by = c->aby[i];
+    if (bx >= c->playerX && bx <= c->playerX + SI_PLAYER_WIDTH && by >= SCREEN_HEIGHT - 40 &&
+        by <= SCREEN_HEIGHT - 40 + SI_PLAYER_HEIGHT) {
+      si_remove(c->abx, c->aby, &c->nab, i);
+      c->lives--;
+      rew -= 50;
+    }
+  }
+  if (c->formY + (SI_ALIEN_ROWS * 8) > SCREEN_HEIGHT - 40) c->lives = 0;
+  int allAliensGone = 1;
+  for (int row = 0; row < SI_ALIEN_ROWS && allAliensGone; row++)
+    for (int col = 0; col < SI_ALIEN_COLS && allAliensGone; col++)
+      if (c->aliens[row][col]) allAliensGone = 0;
+  if (allAliensGone) {
+    rew += 100;
+    for (int row = 0; row < SI_ALIEN_ROWS; row++)
+      for (int col = 0; col < SI_ALIEN_COLS; col++) c->aliens[row][col] = 1;
+    c->formY = 40;
+    c->formX = 10;
+  }
+  *done = c->lives <= 0 || c->steps >= 10000;
+  *reward = rew;
+  return 0;
+}
+
+/* Envs.SpaceInvaders.cs:437-459 */
+static void si_draw_player(uint8_t* screen, int x, int y) {
+  static const uint8_t sprite[6][8] = {{0, 0, 0, 1, 1, 0, 0, 0}, {0, 0, 1, 1, 1, 1, 0, 0}, {0, 0, 1, 1, 1, 1, 0, 0},
+                                       {0, 1, 1, 1, 1, 1, 1, 0}, {1, 1, 1, 1, 1, 1, 1, 1}, {1, 1, 1, 1, 1, 1, 1, 1}};
+  for (int dy = 0; dy < 6; dy++)
+    for (int dx = 0; dx < 8; dx++)
+      if (sprite[dy][dx]) draw_rect_rgb(screen, x + dx, y + dy, 1, 1, 0, 255, 0);
+}
+
+/* Envs.SpaceInvaders.cs:355-435, 480-525.  state image as gxo_vec_get_state lays it out:
+ * reals playerX, formX, formY, 3 player bullets (x, y), 2 alien bullets (x, y);
+ * ints score, lives, frameCounter, moveRight, npb, nab, aliens bits 0..31, bits 32..54, steps */
+void gxo_invaders_render(const double* reals, const int32_t* ints, uint8_t* screen) {
+  static const uint8_t alien[6][6] = {{0, 1, 0, 0, 1, 0}, {0, 0, 1, 1, 0, 0}, {0, 1, 1, 1, 1, 0},
+                                      {1, 1, 0, 0, 1, 1}, {1, 1, 1, 1, 1, 1}, {0, 1, 0, 0, 1, 0}};
+  static const uint8_t rgb[SI_ALIEN_ROWS][3] = {{255, 0, 255}, {0, 255, 255}, {255, 255, 0}, {0, 255, 0}, {255, 0, 0}};
+  const double playerX = reals[0], formX = reals[1], formY = reals[2];
+  const uint64_t bits = (uint64_t)(uint32_t)ints[6] | ((uint64_t)(uint32_t)ints[7] << 32);
+  memset(screen, 0, GXO_PONG_FRAME_BYTES);
+  for (int row = 0; row < SI_ALIEN_ROWS; row++)
+    for (int col = 0; col < SI_ALIEN_COLS; col++)
+      if ((bits >> (row * SI_ALIEN_COLS + col)) & 1u) {
+        int x = (int)(formX + col * 12), y = (int)(formY + row * 10);
+        for (int dy = 0; dy < 6; dy++)
+          for (int dx = 0; dx < 6; dx++)
+            if (alien[dy][dx]) draw_rect_rgb(screen, x + dx, y + dy, 1, 1, rgb[row][0], rgb[row][1], rgb[row][2]);
+      }
+  si_draw_player(screen, (int)playerX, SCREEN_HEIGHT - 40);
+  int npb = ints[4] < 0 ? 0 : (ints[4] > SI_MAX_PLAYER_BULLETS ? SI_MAX_PLAYER_BULLETS : ints[4]);
+  int nab = ints[5] < 0 ? 0 : (ints[5] > SI_MAX_ALIEN_BULLETS ? SI_MAX_ALIEN_BULLETS : ints[5]);
+  for (int i = 0; i < npb; i++)
+    draw_rect_rgb(screen, (int)reals[3 + 2 * i], (int)reals[4 + 2 * i], SI_BULLET_WIDTH, SI_BULLET_HEIGHT, 255, 255, 0);
+  for (int i = 0; i < nab; i++)
+    draw_rect_rgb(screen, (int)reals[9 + 2 * i], (int)reals[10 + 2 * i], SI_BULLET_WIDTH, SI_BULLET_HEIGHT, 255, 0, 0);
+  char str[16];
+  int len = snprintf(str, sizeof str, "%d", ints[0]);
+  for (int i = 0; i < len; i++) draw_digit(screen, str[i], 10 + i * 6, 10);
+  for (int i = 0; i < ints[1]; i++) si_draw_player(screen, (SCREEN_WIDTH - 40) - i * 10, 10);
+  for (int x = 0; x < SCREEN_WIDTH; x++) draw_rect_rgb(screen, x, SCREEN_HEIGHT - 20, 1, 2, 0, 255, 0);
+}
+
+static void invaders_export(const env_obj* e, void* reals, int32_t* ints) {
+  const invaders_t* c = (const invaders_t*)e;
+  double* d = (double*)reals;
+  d[0] = c->playerX; d[1] = c->formX; d[2] = c->formY;
+  for (int i = 0; i < SI_MAX_PLAYER_BULLETS; i++) { d[3 + 2 * i] = c->pbx[i]; d[4 + 2 * i] = c->pby[i]; }
+  for (int i = 0; i < SI_MAX_ALIEN_BULLETS; i++) { d[9 + 2 * i] = c->abx[i]; d[10 + 2 * i] = c->aby[i]; }
+  ints[0] = c->score; ints[1] = c->lives; ints[2] = c->frameCounter; ints[3] = c->moveRight;
+  ints[4] = c->npb; ints[5] = c->nab;
+  uint64_t bits = 0;
+  for (int row = 0; row < SI_ALIEN_ROWS; row++)
+    for (int col = 0; col < SI_ALIEN_COLS; col++)
+      if (c->aliens[row][col]) bits |= (uint64_t)1 << (row * SI_ALIEN_COLS + col);
+  ints[6] = (int32_t)(uint32_t)bits;
+  ints[7] = (int32_t)(uint32_t)(bits >> 32);
+  ints[8] = c->steps;
+}
+static void invaders_import(env_obj* e, const void* reals, const int32_t* ints) {
+  invaders_t* c = (invaders_t*)e;
+  const double* d = (const double*)reals;
+  c->playerX = d[0]; c->formX = d[1]; c->formY = d[2];
+  for (int i = 0; i < SI_MAX_PLAYER_BULLETS; i++) { c->pbx[i] = d[3 + 2 * i]; c->pby[i] = d[4 + 2 * i]; }
+  for (int i = 0; i < SI_MAX_ALIEN_BULLETS; i++) { c->abx[i] = d[9 + 2 * i]; c->aby[i] = d[10 + 2 * i]; }
+  c->score = ints[0]; c->lives = ints[1]; c->frameCounter = ints[2]; c->moveRight = ints[3] != 0;
+  c->npb = ints[4] < 0 ? 0 : (ints[4] > SI_MAX_PLAYER_BULLETS ? SI_MAX_PLAYER_BULLETS : ints[4]);
+  c->nab = ints[5] < 0 ? 0 : (ints[5] > SI_MAX_ALIEN_BULLETS ? SI_MAX_ALIEN_BULLETS : ints[5]);
+  const uint64_t bits = (uint64_t)(uint32_t)ints[6] | ((uint64_t)(uint32_t)ints[7] << 32);
+  for (int row = 0; row < SI_ALIEN_ROWS; row++)
+    for (int col = 0; col < SI_ALIEN_COLS; col++)
+      c->aliens[row][col] = (uint8_t)((bits >> (row * SI_ALIEN_COLS + col)) & 1u);
+  c->steps = ints[8];
+}
+static const env_vtbl invaders_vt = {invaders_reset, invaders_step, invaders_export, invaders_import, sizeof(invaders_t)};
+
 /* ======================================================================
  * Wrappers and the batched driver.
  * ====================================================================== */
@@ -1165,6 +1409,7 @@ gxo_vec* gxo_vec_create(int env_id, uint64_t num_envs, uint64_t seed, uint32_t f
     case GXO_DUMMY: vt = &dummy_vt; v->n_real = 0; v->n_int = 2; v->obs_dim = 1; break;
     case GXO_PONG: vt = &pong_vt; v->n_real = 6; v->real_is_f64 = 1; v->n_int = 3; v->obs_dim = GXO_PONG_FRAME_BYTES; break;
     case GXO_BREAKOUT: vt = &breakout_vt; v->n_real = 5; v->real_is_f64 = 1; v->n_int = 8; v->obs_dim = GXO_PONG_FRAME_BYTES; break;
+    case GXO_SPACEINVADERS: vt = &invaders_vt; v->n_real = 13; v->real_is_f64 = 1; v->n_int = 9; v->obs_dim = GXO_PONG_FRAME_BYTES; break;
   }
   if (env_id == GXO_FROZENLAKE || env_id == GXO_CLIFFWALKING) {
     grid_desc* g = (grid_desc*)calloc(1, sizeof *g);
@@ -1197,9 +1442,9 @@ gxo_vec* gxo_vec_create(int env_id, uint64_t num_envs, uint64_t seed, uint32_t f
   v->cur_reward = (double*)calloc(num_envs ? num_envs : 1, sizeof(double));
   v->cur_length = (int32_t*)calloc(num_envs ? num_envs : 1, sizeof(int32_t));
   v->episodes = (episode_list*)calloc(num_envs ? num_envs : 1, sizeof(episode_list));
-  if (env_id == GXO_PONG || env_id == GXO_BREAKOUT) {
-    /* The Pong and Breakout constructors call Reset() (Envs.Pong.cs:47-52,
-     * Envs.Breakout.cs:54-60).  Pong's draw is unobservable once the batch is
+  if (env_id == GXO_PONG || env_id == GXO_BREAKOUT || env_id == GXO_SPACEINVADERS) {
+    /* The Pong, Breakout and SpaceInvaders constructors call Reset() (Envs.Pong.cs:47-52,
+     * Envs.Breakout.cs:54-60, Envs.SpaceInvaders.cs:59-67).  Pong's draw is unobservable once the batch is
      * reset, so construction leaves tick at 0. */
     for (uint64_t i = 0; i < num_envs; i++) {
       rng_ctx r = {seed, env_index_base + i, 0};
@@ -1276,7 +1521,7 @@ static int vec_step_impl(gxo_vec* v, const void* actions, int random_policy, voi
           af = gxo_box_sample(u, -2.0f, 2.0f);
           break;
         default: {
-          static const int nact[GXO_NUM_ENVS] = {2, 3, 0, 0, 3, 4, 6, 4, 4, 3, 4};
+          static const int nact[GXO_NUM_ENVS] = {2, 3, 0, 0, 3, 4, 6, 4, 4, 3, 4, 6};
           ai = gxo_rng_below(r.seed, r.env_index, r.tick, 2, 0, nact[v->env_id]);
         }
       }
@@ -1329,8 +1574,8 @@ void gxo_vec_get_state(const gxo_vec* v, void* buf) {
   size_t rsz = v->real_is_f64 ? 8 : 4;
   char* reals = (char*)buf;
   int32_t* ints = (int32_t*)(reals + (size_t)v->n * v->n_real * rsz);
-  double tmp[8];
-  int32_t itmp[8];
+  double tmp[16];
+  int32_t itmp[12];
   for (uint64_t i = 0; i < v->n; i++) {
     v->envs[i]->vt->export_state(v->envs[i], tmp, itmp);
     for (int k = 0; k < v->n_real; k++)
@@ -1343,8 +1588,8 @@ void gxo_vec_set_state(gxo_vec* v, const void* buf) {
   size_t rsz = v->real_is_f64 ? 8 : 4;
   const char* reals = (const char*)buf;
   const int32_t* ints = (const int32_t*)(reals + (size_t)v->n * v->n_real * rsz);
-  double tmp[8];
-  int32_t itmp[8];
+  double tmp[16];
+  int32_t itmp[12];
   for (uint64_t i = 0; i < v->n; i++) {
     for (int k = 0; k < v->n_real; k++)
       memcpy((char*)tmp + (size_t)k * rsz, reals + ((size_t)k * v->n + i) * rsz, rsz);
@@ -1359,8 +1604,8 @@ void gxo_vec_set_state(gxo_vec* v, const void* buf) {
 }
 
 void gxo_vec_get_obs(const gxo_vec* v, void* buf) {
-  double tmp[8];
-  int32_t itmp[8];
+  double tmp[16];
+  int32_t itmp[12];
   for (uint64_t i = 0; i < v->n; i++) {
     v->envs[i]->vt->export_state(v->envs[i], tmp, itmp);
     if (v->env_id == GXO_PONG) {
@@ -1369,6 +1614,8 @@ void gxo_vec_get_obs(const gxo_vec* v, void* buf) {
     } else if (v->env_id == GXO_BREAKOUT) {
       gxo_breakout_render(tmp[0], tmp[1], tmp[4], itmp[2], itmp[0], itmp[1], (const uint32_t*)&itmp[3],
                           (uint8_t*)buf + (size_t)i * GXO_PONG_FRAME_BYTES);
+    } else if (v->env_id == GXO_SPACEINVADERS) {
+      gxo_invaders_render(tmp, itmp, (uint8_t*)buf + (size_t)i * GXO_PONG_FRAME_BYTES);
     } else if (v->env_id == GXO_ACROBOT && v->real_is_f64) {
       float* o = (float*)buf;
       o[0 * v->n + i] = (float)cos(tmp[0]);
@@ -1415,7 +1662,7 @@ void gxo_vec_episode_get(const gxo_vec* v, uint64_t env, size_t k, double* ret, 
  * (Envs.CartPole.cs:73, VectorEnv.cs:30-32), so it flatters the reference.
  * ====================================================================== */
 typedef struct step_result {
-  double state[6];
+  double state[16];
   double reward;
   int done;
   void* info;
@@ -1427,7 +1674,7 @@ double gxo_bench_reference_shaped(int env_id, uint64_t num_envs, int steps, uint
   if (!v) return -1.0;
   gxo_vec_reset(v);
   void* actions = malloc(num_envs * 4);
-  static const int nact[GXO_NUM_ENVS] = {2, 3, 0, 0, 3, 4, 6, 4, 4, 3, 4};
+  static const int nact[GXO_NUM_ENVS] = {2, 3, 0, 0, 3, 4, 6, 4, 4, 3, 4, 6};
   for (uint64_t i = 0; i < num_envs; i++) {
     if (v->action_is_float) {
       float lim = env_id == GXO_PENDULUM ? 2.0f : 1.0f;
@@ -1437,7 +1684,7 @@ double gxo_bench_reference_shaped(int env_id, uint64_t num_envs, int steps, uint
     }
   }
   /* every Pong object owns its 210x160x3 `_screen` (Envs.Pong.cs:49) */
-  uint8_t* screens = (env_id == GXO_PONG || env_id == GXO_BREAKOUT) ? (uint8_t*)malloc(num_envs * (size_t)GXO_PONG_FRAME_BYTES) : NULL;
+  uint8_t* screens = (env_id == GXO_PONG || env_id == GXO_BREAKOUT || env_id == GXO_SPACEINVADERS) ? (uint8_t*)malloc(num_envs * (size_t)GXO_PONG_FRAME_BYTES) : NULL;
   double acc = 0.0;
   struct timespec t0, t1;
   clock_gettime(CLOCK_MONOTONIC, &t0);
@@ -1447,7 +1694,7 @@ double gxo_bench_reference_shaped(int env_id, uint64_t num_envs, int steps, uint
       rng_ctx r = {seed, i, v->tick};
       env_obj* e = v->envs[i];
       const void* ap = (const char*)actions + i * 4;
-      int32_t ints[8];
+      int32_t ints[12];
       e->vt->step(e, ap, &r, &results[i].reward, &results[i].done);
       e->vt->export_state(e, results[i].state, ints);
       results[i].info = NULL;
@@ -1457,9 +1704,11 @@ double gxo_bench_reference_shaped(int env_id, uint64_t num_envs, int steps, uint
         e->vt->export_state(e, results[i].state, ints);
         if (env_id == GXO_PONG)
           gxo_pong_render(st[0], st[1], st[4], st[5], ints[0], ints[1], screens + i * (size_t)GXO_PONG_FRAME_BYTES);
-        else
+        else if (env_id == GXO_BREAKOUT)
           gxo_breakout_render(st[0], st[1], st[4], ints[2], ints[0], ints[1], (const uint32_t*)&ints[3],
                               screens + i * (size_t)GXO_PONG_FRAME_BYTES);
+        else
+          gxo_invaders_render(st, ints, screens + i * (size_t)GXO_PONG_FRAME_BYTES);
         acc += screens[i * (size_t)GXO_PONG_FRAME_BYTES + 60];
       }
     }
@@ -1518,7 +1767,7 @@ double gxo_bench_flat_threads(int env_id, uint64_t num_envs, int steps, int thre
     return -1.0;
   }
   const env_vtbl* vt = v->envs[0]->vt;
-  static const int nact[GXO_NUM_ENVS] = {2, 3, 0, 0, 3, 4, 6, 4, 4, 3, 4};
+  static const int nact[GXO_NUM_ENVS] = {2, 3, 0, 0, 3, 4, 6, 4, 4, 3, 4, 6};
   char* actions = (char*)malloc(num_envs * 4);
   for (uint64_t i = 0; i < num_envs; i++) {
     if (v->action_is_float) {

@@ -42,7 +42,8 @@ enum {
   GXO_PONG = 8,          /* Envs.Pong.cs */
   GXO_DUMMY = 9,         /* DummyEnv.cs */
   GXO_BREAKOUT = 10,     /* Envs.Breakout.cs */
-  GXO_NUM_ENVS = 11
+  GXO_SPACEINVADERS = 11, /* Envs.SpaceInvaders.cs */
+  GXO_NUM_ENVS = 12
 };
 
 /* Wrapper / engine flags. */
@@ -116,6 +117,10 @@ void gxo_pong_render(double ball_x, double ball_y, double left_y, double right_y
 /* Breakout raster alone (Envs.Breakout.cs:229-344).  bricks: bit row*18+col. */
 void gxo_breakout_render(double ball_x, double ball_y, double paddle_x, int ball_stuck, int score, int lives,
                          const uint32_t bricks[4], uint8_t* frame);
+
+/* SpaceInvaders raster alone (Envs.SpaceInvaders.cs:355-525) from one env's state image:
+ * 13 reals, 9 ints in the order of gxo_vec_get_state. */
+void gxo_invaders_render(const double* reals, const int32_t* ints, uint8_t* frame);
 
 /* ---- CPU baseline: reference-shaped sequential loop over heap objects with a
  * virtual Step (VectorEnv.cs:28-34), single thread.  Runs `steps` batched

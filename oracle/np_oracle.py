@@ -448,6 +448,169 @@ def breakout_frame(bx, by, px, stuck, score, lives, words):
     return f.reshape(-1)
 
 
+# ----------------------------------------------------------- SpaceInvaders
+class InvadersGame:
+    """Envs.SpaceInvaders.cs:12-541 for one env, written with Python lists where the source uses
+    List<(double,double)> (so removal and append order are the source's own).  Draws come from
+    the counter RNG: stream 1, draw 0 = NextDouble() < 0.3, draw 1 = Next(shooters.Count)."""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):  # :69-96
+        self.aliens = [[True] * 11 for _ in range(5)]
+        self.player_x = 160 / 2.0 - 8 / 2.0
+        self.form_x, self.form_y, self.move_right = 10.0, 40.0, True
+        self.player_bullets, self.alien_bullets = [], []
+        self.score, self.lives, self.steps, self.frame = 0, 3, 0, 0
+
+    def _fire(self):  # :192-199
+        if len(self.player_bullets) < 3:
+            self.player_bullets.append((self.player_x + 8 / 2.0, 210.0 - 40))
+
+    def step(self, action, seed, env, tick):  # :98-190
+        self.steps += 1
+        self.frame += 1
+        reward = 0.0
+        if action == 1:
+            self._fire()
+        elif action == 2:
+            self.player_x = min(160.0 - 8, self.player_x + 3.0)
+        elif action == 3:
+            self.player_x = max(0.0, self.player_x - 3.0)
+        elif action == 4:
+            self.player_x = min(160.0 - 8, self.player_x + 3.0)
+            self._fire()
+        elif action == 5:
+            self.player_x = max(0.0, self.player_x - 3.0)
+            self._fire()
+        for i in range(len(self.player_bullets) - 1, -1, -1):  # :229-241
+            x, y = self.player_bullets[i]
+            y -= 6.0
+            if y < 0:
+                del self.player_bullets[i]
+            else:
+                self.player_bullets[i] = (x, y)
+        for i in range(len(self.alien_bullets) - 1, -1, -1):  # :244-256
+            x, y = self.alien_bullets[i]
+            y += 6.0 * 0.7
+            if y > 210:
+                del self.alien_bullets[i]
+            else:
+                self.alien_bullets[i] = (x, y)
+        if self.frame % 10 == 0:  # :259-279
+            if self.move_right:
+                self.form_x += 0.5
+                if self.form_x + 11 * 12 > 160 - 10:
+                    self.move_right = False
+                    self.form_y += 8.0
+            else:
+                self.form_x -= 0.5
+                if self.form_x < 10:
+                    self.move_right = True
+                    self.form_y += 8.0
+        e = np.array([env], np.uint64)
+        if self.frame % 60 == 0 and float(rng_uniform(seed, e, tick, 1, 0)[0]) < 0.3:  # :136-139, :201-224
+            shooters = []
+            for col in range(11):
+                for row in range(4, -1, -1):
+                    if self.aliens[row][col]:
+                        shooters.append((row, col))
+                        break
+            if shooters:
+                row, col = shooters[int(rng_below(seed, e, tick, 1, 1, len(shooters))[0])]
+                if len(self.alien_bullets) < 2:  # capacity of the state image (never reached in play)
+                    self.alien_bullets.append((self.form_x + col * 12 + 6 / 2.0, self.form_y + row * 10 + 6))
+        for i in range(len(self.player_bullets) - 1, -1, -1):  # :286-323
+            bx, by = self.player_bullets[i]
+            hit = False
+            for row in range(5):
+                for col in range(11):
+                    if self.aliens[row][col]:
+                        ax, ay = self.form_x + col * 12, self.form_y + row * 10
+                        if ax <= bx <= ax + 6 and ay <= by <= ay + 6:
+                            self.aliens[row][col] = False
+                            del self.player_bullets[i]
+                            pts = {0: 30, 1: 20, 2: 20}.get(row, 10)
+                            self.score += pts
+                            reward += pts
+                            hit = True
+                            break
+                if hit:
+                    break
+        for i in range(len(self.alien_bullets) - 1, -1, -1):  # :326-336
+            bx, by = self.alien_bullets[i]
+            if self.player_x <= bx <= self.player_x + 8 and 210 - 40 <= by <= 210 - 40 + 6:
+                del self.alien_bullets[i]
+                self.lives -= 1
+                reward -= 50
+        if self.form_y + 5 * 8 > 210 - 40:  # :145-148
+            self.lives = 0
+        if not any(any(r) for r in self.aliens):  # :151-174
+            reward += 100
+            self.aliens = [[True] * 11 for _ in range(5)]
+            self.form_y, self.form_x = 40.0, 10.0
+        return reward, self.lives <= 0 or self.steps >= 10000
+
+    def image(self):
+        """(13 reals, 9 ints) as gx_vec_get_state lays one env out"""
+        pb = self.player_bullets + [(0.0, 0.0)] * (3 - len(self.player_bullets))
+        ab = self.alien_bullets + [(0.0, 0.0)] * (2 - len(self.alien_bullets))
+        reals = [self.player_x, self.form_x, self.form_y] + [v for b in pb for v in b] + [v for b in ab for v in b]
+        bits = 0
+        for row in range(5):
+            for col in range(11):
+                if self.aliens[row][col]:
+                    bits |= 1 << (row * 11 + col)
+        ints = np.array([self.score, self.lives, self.frame, int(self.move_right), len(self.player_bullets), len(self.alien_bullets),
+                         bits & 0xFFFFFFFF, bits >> 32, self.steps], np.int64).astype(np.uint32).view(np.int32)
+        return np.array(reals, f64), ints
+
+    def load(self, reals, ints):
+        self.player_x, self.form_x, self.form_y = (float(v) for v in reals[:3])
+        npb, nab = min(max(int(ints[4]), 0), 3), min(max(int(ints[5]), 0), 2)
+        self.player_bullets = [(float(reals[3 + 2 * i]), float(reals[4 + 2 * i])) for i in range(npb)]
+        self.alien_bullets = [(float(reals[9 + 2 * i]), float(reals[10 + 2 * i])) for i in range(nab)]
+        self.score, self.lives, self.frame, self.move_right = int(ints[0]), int(ints[1]), int(ints[2]), bool(ints[3])
+        bits = (int(ints[6]) & 0xFFFFFFFF) | ((int(ints[7]) & 0xFFFFFFFF) << 32)
+        self.aliens = [[bool((bits >> (row * 11 + col)) & 1) for col in range(11)] for row in range(5)]
+        self.steps = int(ints[8])
+
+    _ALIEN = ["010010", "001100", "011110", "110011", "111111", "010010"]  # :416-423
+    _PLAYER = ["00011000", "00111100", "00111100", "01111110", "11111111", "11111111"]  # :440-447
+    _ROW_RGB = [(255, 0, 255), (0, 255, 255), (255, 255, 0), (0, 255, 0), (255, 0, 0)]  # :374-378
+
+    def frame_bytes(self):  # :355-411, painter's order
+        f = np.zeros((210, 160, 3), np.uint8)
+
+        def rect(x, y, w, h, rgb):
+            f[max(y, 0):max(min(y + h, 210), 0), max(x, 0):max(min(x + w, 160), 0)] = rgb
+
+        def sprite(rows, x, y, rgb):
+            for dy, r in enumerate(rows):
+                for dx, bit in enumerate(r):
+                    if bit == "1":
+                        rect(x + dx, y + dy, 1, 1, rgb)
+
+        for row in range(5):
+            for col in range(11):
+                if self.aliens[row][col]:
+                    sprite(self._ALIEN, int(self.form_x + col * 12), int(self.form_y + row * 10), self._ROW_RGB[row])
+        sprite(self._PLAYER, int(self.player_x), 210 - 40, (0, 255, 0))
+        for x, y in self.player_bullets:
+            rect(int(x), int(y), 2, 4, (255, 255, 0))
+        for x, y in self.alien_bullets:
+            rect(int(x), int(y), 2, 4, (255, 0, 0))
+        for i, ch in enumerate(str(int(self.score))):
+            if ch.isdigit():
+                sprite(_GLYPHS[int(ch)], 10 + i * 6, 10, (255, 255, 255))
+        for i in range(self.lives):
+            sprite(self._PLAYER, 160 - 40 - i * 10, 10, (0, 255, 0))
+        for x in range(160):
+            rect(x, 210 - 20, 1, 2, (0, 255, 0))
+        return f.reshape(-1)
+
+
 # ---------------------------------------------------------------- wrappers
 class RecordEpisodeStatistics:
     """EnvWrapper.cs:23-58 for one env index; `step` takes the inner result."""

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libgym_oracle.so")
 
 (CARTPOLE, MOUNTAINCAR, MOUNTAINCAR_CONT, PENDULUM, ACROBOT, FROZENLAKE, TAXI, CLIFFWALKING, PONG, DUMMY,
- BREAKOUT) = range(11)
+ BREAKOUT, SPACEINVADERS) = range(12)
 AUTORESET, RECORD_STATS, SLIPPERY, TAXI_FULL, ACROBOT_RK4 = 1, 2, 4, 8, 16
 PONG_FRAME_BYTES = 210 * 160 * 3
 FLOAT_ACTION = {MOUNTAINCAR_CONT, PENDULUM}
@@ -87,6 +87,7 @@ def lib():
     L.gxo_vec_episode_count.argtypes = [vp, u64]
     L.gxo_vec_episode_get.argtypes = [vp, u64, C.c_size_t, C.POINTER(dbl), C.POINTER(i32)]
     L.gxo_pong_render.argtypes = [dbl, dbl, dbl, dbl, C.c_int, C.c_int, vp]
+    L.gxo_invaders_render.argtypes = [vp, vp, vp]
     L.gxo_breakout_render.argtypes = [dbl, dbl, dbl, C.c_int, C.c_int, C.c_int, vp, vp]
     L.gxo_bench_reference_shaped.restype = dbl
     L.gxo_bench_reference_shaped.argtypes = [C.c_int, u64, C.c_int, u64, C.POINTER(u64), C.POINTER(dbl)]
@@ -180,7 +181,7 @@ class OracleVec:
         self.set_state_raw(np.concatenate([r, i]))
 
     def get_obs(self):
-        if self.env_id in (PONG, BREAKOUT):
+        if self.env_id in (PONG, BREAKOUT, SPACEINVADERS):
             out = np.empty((self.n, PONG_FRAME_BYTES), np.uint8)
         elif self.n_real > 0:
             out = np.empty((self.obs_dim, self.n), np.float32)
@@ -236,6 +237,16 @@ def breakout_render(ball_x, ball_y, paddle_x, ball_stuck, score, lives, bricks):
     w = np.ascontiguousarray(bricks, dtype=np.uint32)
     assert w.shape == (4,)
     lib().gxo_breakout_render(ball_x, ball_y, paddle_x, int(ball_stuck), score, lives, _ptr(w), _ptr(out))
+    return out
+
+
+def invaders_render(reals, ints):
+    """reals: 13 float64, ints: 9 int32 (one env's state image)"""
+    out = np.empty(PONG_FRAME_BYTES, np.uint8)
+    r = np.ascontiguousarray(reals, dtype=np.float64)
+    i = np.ascontiguousarray(ints, dtype=np.int32)
+    assert r.shape == (13,) and i.shape == (9,)
+    lib().gxo_invaders_render(_ptr(r), _ptr(i), _ptr(out))
     return out
 
 

@@ -5,7 +5,7 @@ envs, so these fixtures are outputs of the oracle (itself pinned by hand-derived
 and by the independent numpy restatement).  Per env: 256 start states x 64 steps of random
 actions -- initial SoA state, the actions, every reward / done flag and the final state; for
 Pong additionally 8 frames as bit masks (a frame is 0/255 with equal channels), for Breakout
-as indices into its 8-colour palette.
+and SpaceInvaders as indices into a small palette.
 
     python tests/golden/make_golden.py
 """
@@ -21,7 +21,7 @@ from oracle import oracle as O  # noqa: E402
 N, T, SEED = 256, 64, 20250614
 # black, white and the six brick rows (Envs.Breakout.cs:248-253)
 BREAKOUT_PALETTE = np.array([[0, 0, 0], [255, 255, 255], [255, 0, 0], [255, 165, 0], [255, 255, 0], [0, 255, 0], [0, 0, 255],
-                             [128, 0, 128]], np.uint8)
+                             [128, 0, 128], [255, 0, 255], [0, 255, 255]], np.uint8)  # + SpaceInvaders' magenta, cyan
 
 
 def palette_index(frames):
@@ -41,13 +41,14 @@ CASES = [
     ("frozenlake_8x8", O.FROZENLAKE, 4, {"map_rows": ["SFFFFFFF", "FFFFFFFF", "FFFHFFFF", "FFFFFHFF", "FFFHFFFF", "FHHFFFHF", "FHFFHFHF", "FFFHFFFG"]}),
     ("taxi", O.TAXI, 6, {}), ("cliffwalking", O.CLIFFWALKING, 4, {}), ("pong", O.PONG, 4, {}),
     ("breakout", O.BREAKOUT, 4, {}),
+    ("spaceinvaders", O.SPACEINVADERS, 6, {}),
 ]
 
 
 def main():
     for name, eid, nact, kw in CASES:
         rng = np.random.default_rng(sum(map(ord, name)))
-        steps = {"pong": 400, "breakout": 600}.get(name, T)
+        steps = {"pong": 400, "breakout": 600, "spaceinvaders": 900}.get(name, T)
         v = O.OracleVec(eid, N, seed=SEED, **kw)
         v.reset()
         init = v.get_state_raw().copy()
@@ -64,13 +65,13 @@ def main():
                 f = v.get_obs()[:8]
                 assert ((f == 0) | (f == 255)).all() and (f[:, 0::3] == f[:, 1::3]).all() and (f[:, 0::3] == f[:, 2::3]).all()
                 frames.append(np.packbits(f[:, 0::3] == 255, axis=1))
-            if name == "breakout" and t % 150 == 149:
+            if name in ("breakout", "spaceinvaders") and t % 150 == 149:
                 frames.append(palette_index(v.get_obs()[:8]))
         out = dict(init=init, actions=actions, rewards=rewards, dones=dones, final=v.get_state_raw(), seed=np.int64(SEED))
         if kw.get("map_rows"):
             out["map_rows"] = np.array("/".join(kw["map_rows"]))
         if frames:
-            out["frame_index" if name == "breakout" else "frame_masks"] = np.stack(frames)
+            out["frame_index" if name in ("breakout", "spaceinvaders") else "frame_masks"] = np.stack(frames)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
         print(name, {k: getattr(x, "shape", None) for k, x in out.items()})
 

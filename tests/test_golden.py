@@ -12,8 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 FILES = sorted(glob.glob(os.path.join(HERE, "golden", "*.npz")))
 ENV_OF = {"cartpole": "CARTPOLE", "mountaincar": "MOUNTAINCAR", "mountaincar_cont": "MOUNTAINCAR_CONT", "pendulum": "PENDULUM",
           "acrobot": "ACROBOT", "frozenlake": "FROZENLAKE", "frozenlake_8x8": "FROZENLAKE", "taxi": "TAXI",
-          "cliffwalking": "CLIFFWALKING", "pong": "PONG", "breakout": "BREAKOUT"}
-EXACT = {"frozenlake", "frozenlake_8x8", "taxi", "cliffwalking", "pong", "breakout"}
+          "cliffwalking": "CLIFFWALKING", "pong": "PONG", "breakout": "BREAKOUT", "spaceinvaders": "SPACEINVADERS"}
+EXACT = {"frozenlake", "frozenlake_8x8", "taxi", "cliffwalking", "pong", "breakout", "spaceinvaders"}
 
 
 def load(path):
@@ -23,13 +23,16 @@ def load(path):
     return name, z, rows
 
 
+INDEXED = ("breakout", "spaceinvaders")  # frames stored as palette indices
+
+
 def palette_index(frames):
     from golden.make_golden import palette_index as f
     return f(frames)
 
 
 def test_fixtures_present():
-    assert len(FILES) == 11
+    assert len(FILES) == 12
 
 
 @pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f)[:-4] for f in FILES])
@@ -43,7 +46,7 @@ def test_oracle_reproduces_golden(oracle, path):
     for t in range(z["actions"].shape[0]):
         r, d, _ = v.step(z["actions"][t])
         assert np.array_equal(r, z["rewards"][t]) and np.array_equal(d, z["dones"][t])
-        if name == "breakout" and t % 150 == 149:
+        if name in INDEXED and t % 150 == 149:
             frames.append(palette_index(v.get_obs()[:8]))
     assert np.array_equal(v.get_state_raw(), z["final"])
     if frames:
@@ -64,7 +67,7 @@ def test_gpu_reproduces_golden(path):
     frames = []
     mismatched = 0
     for t in range(z["actions"].shape[0]):
-        want_obs = (name == "pong" and t % 50 == 49) or (name == "breakout" and t % 150 == 149)
+        want_obs = (name == "pong" and t % 50 == 49) or (name in INDEXED and t % 150 == 149)
         obs, r, d, _ = g.step_host(z["actions"][t], want_obs=want_obs)
         if name in EXACT:
             assert np.array_equal(r.astype(np.float64), z["rewards"][t]) and np.array_equal(d, z["dones"][t]), t
@@ -72,7 +75,7 @@ def test_gpu_reproduces_golden(path):
             bad = r.astype(np.float64) != z["rewards"][t]
             mismatched += int(bad.sum())
             assert np.allclose(r, z["rewards"][t], rtol=1e-5, atol=1e-6)
-        if want_obs and name == "breakout":
+        if want_obs and name in INDEXED:
             frames.append(palette_index(obs[:8]))
         elif want_obs:
             f = obs[:8]
@@ -89,4 +92,4 @@ def test_gpu_reproduces_golden(path):
         assert same or mismatched > 0 or np.allclose(a, b, rtol=1e-3, atol=1e-3), "state diverged"
         assert same, "golden continuous-control trajectory not bit-identical (%d reward mismatches)" % mismatched
     if frames:
-        assert np.array_equal(np.stack(frames), z["frame_index" if name == "breakout" else "frame_masks"])
+        assert np.array_equal(np.stack(frames), z["frame_index" if name in INDEXED else "frame_masks"])

@@ -136,6 +136,33 @@ def test_breakout_65536_frames(oracle):
         assert bool(ok.all()), row
 
 
+def test_invaders_65536_frames(oracle):
+    import torch
+    n, k, base, width = 65536, 130, 41000, 48
+    g = DeviceBatch(ctx(), L.ENV_SPACEINVADERS, n, seed=6, flags=L.AUTORESET | L.RECORD_STATS)
+    o = oracle.OracleVec(oracle.SPACEINVADERS, width, seed=6, flags=oracle.AUTORESET | oracle.RECORD_STATS, env_index_base=base)
+    g.reset(); o.reset()
+    for _ in range(k):
+        g.step_random(); o.step_random()
+    g.ctx.synchronize()
+    v = torch_views(g)
+    assert np.array_equal(v["obs"][base:base + width].cpu().numpy(), o.get_obs())
+    f = v["obs"].view(n, 210, 160, 3)
+    st, re = v["state_int"], v["state_real"]
+    # the ground line is green in all 65 536 frames, the rows under it are black
+    assert bool((f[:, 190:192, :, 1] == 255).all()) and int(f[:, 190:192, :, 0].max()) == 0 and int(f[:, 192:].max()) == 0
+    # conservation: the score is what the missing aliens of the first wave pay (30/20/20/10/10 per row);
+    # 130 steps are too few to clear a wave
+    bits_ = (st[6, :n].to(torch.int64) & 0xFFFFFFFF) | ((st[7, :n].to(torch.int64) & 0xFFFFFFFF) << 32)
+    score = torch.zeros(n, dtype=torch.int64, device=bits_.device)
+    for row, pts in enumerate((30, 20, 20, 10, 10)):
+        for col in range(11):
+            score += (1 - ((bits_ >> (row * 11 + col)) & 1)) * pts
+    assert torch.equal(score, st[0, :n].to(torch.int64))
+    assert int(st[4, :n].max()) <= 3 and int(st[5, :n].max()) <= 1 and int(st[1, :n].min()) >= 1
+    assert float(re[0, :n].min()) >= 0.0 and float(re[0, :n].max()) <= 152.0
+
+
 def test_acrobot_16mi_window_and_rk4_rollout(oracle):
     g, v = _window_matches_oracle(oracle, L.ENV_ACROBOT, N16, base=1 << 23, width=2048, k=6, seed=4, flags=FUSED)
     g.close()

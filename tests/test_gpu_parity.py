@@ -42,7 +42,7 @@ def compare_step(g, o, a, t, exact):
     return n
 
 
-@pytest.mark.parametrize("env_id", CLASSIC + TABULAR + [L.ENV_PONG, L.ENV_BREAKOUT])
+@pytest.mark.parametrize("env_id", CLASSIC + TABULAR + [L.ENV_PONG, L.ENV_BREAKOUT, L.ENV_SPACEINVADERS])
 def test_reset_matches_oracle(oracle, env_id):
     g, o = make_pair(oracle, env_id, 1000, seed=77, base=5)
     g.reset(); o.reset()
@@ -51,7 +51,7 @@ def test_reset_matches_oracle(oracle, env_id):
     g.reset(); o.reset()  # second reset uses a new tick, hence new draws
     gr2, _ = g.get_state(); orr2, _ = o.get_state()
     assert np.array_equal(bits(gr2), bits(orr2))
-    if gr.size and env_id not in (L.ENV_PONG, L.ENV_BREAKOUT):
+    if gr.size and env_id not in (L.ENV_PONG, L.ENV_BREAKOUT, L.ENV_SPACEINVADERS):
         assert not np.array_equal(gr, gr2)
     assert np.array_equal(bits(g.get_obs()), bits(o.get_obs()))
 
@@ -197,6 +197,79 @@ def test_pong_frames_edge_states(oracle):
     assert np.array_equal(g.get_obs(), o.get_obs())
 
 
+def _invaders_actions(rng, reals, ints, n):
+    """odd envs act at random (with out-of-range actions); even envs move under the nearest occupied
+    column and fire, which clears waves and draws alien fire onto the cannon"""
+    a = rng.integers(-1, 8, n).astype(np.int32)
+    bits_ = (ints[6].astype(np.int64) & 0xFFFFFFFF) | ((ints[7].astype(np.int64) & 0xFFFFFFFF) << 32)
+    for i in range(0, n, 2):
+        cols = [c for c in range(11) if any((int(bits_[i]) >> (r * 11 + c)) & 1 for r in range(5))]
+        if not cols:
+            a[i] = 1
+            continue
+        gun = reals[0, i] + 4.0
+        target = min((reals[1, i] + c * 12 + 3.0 for c in cols), key=lambda x: abs(x - gun))
+        a[i] = 4 if target > gun + 2 else (5 if target < gun - 2 else 1)
+    return a
+
+
+def test_invaders_state_and_frames_bit_exact(oracle):
+    n, steps = 66, 2400
+    g, o = make_pair(oracle, L.ENV_SPACEINVADERS, n, seed=8)
+    assert np.array_equal(g.get_obs(), o.get_obs())  # the constructor resets (Envs.SpaceInvaders.cs:59-67)
+    g.reset(); o.reset()
+    assert np.array_equal(g.get_obs(), o.get_obs())
+    rng = np.random.default_rng(4)
+    total = np.zeros(n)
+    waves = hit = fired = 0
+    for t in range(steps):
+        reals, ints = o.get_state()
+        fired += int((ints[5] > 0).sum())
+        a = _invaders_actions(rng, reals, ints, n)
+        obs, rew, done, _ = g.step_host(a, want_obs=(t % 200 == 0 or t == 37))
+        orew, odone, _ = o.step(a)
+        assert np.array_equal(rew.astype(np.float64), orew) and np.array_equal(done, odone), t
+        waves += int((orew >= 100).sum()); hit += int((orew < 0).sum())
+        if obs is not None:
+            assert np.array_equal(obs, o.get_obs()), "frames differ at step %d" % t
+        if t % 100 == 99:
+            gr, gi = g.get_state(); orr, oi = o.get_state()
+            assert np.array_equal(bits(gr), bits(orr)) and np.array_equal(gi, oi), t
+    gr, gi = g.get_state(); orr, oi = o.get_state()
+    assert np.array_equal(bits(gr), bits(orr)) and np.array_equal(gi, oi)
+    assert waves > 0 and hit > 0 and fired > 0  # cleared waves, alien fire and hits on the cannon all occurred
+    assert np.array_equal(g.get_obs(), o.get_obs())
+
+
+def test_invaders_edge_frames_and_injected_states(oracle):
+    """sprites clipped at every border, bullets over sprites, full bullet lists, many-digit and negative scores,
+    the formation at its lowest, one alien left"""
+    #        playerX formX formY  pb0        pb1           pb2          ab0          ab1      | score lives frame right npb nab bits0 bits1 steps
+    cases = [
+        [0.0, 10.0, 40.0, 3.9, 0.0, 157.2, 208.9, 80.0, 100.0, 12.0, 42.0, 159.0, 170.5, 123456, 3, 7, 1, 3, 2, -1, 0x7FFFFF, 7],
+        [152.0, 27.5, 120.0, 30.0, 121.0, 0, 0, 0, 0, 156.0, 172.0, 0, 0, -50, 1, 9, 0, 1, 1, 0x55555555, 0x2AAAAA, 9],
+        [75.4, -3.0, 161.0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 990, 0, 0, 1, 0, 0, -1, 0x7FFFFF, 0],
+        [80.0, 150.0, 5.0, 11.0, 11.0, 121.0, 12.0, 100.0, 190.0, 50.0, 189.5, 20.0, 12.0, 2147483647, 13, 5, 1, 3, 2, 1 << 10, 1 << 22, 1],
+        [76.0, 18.0, 128.0, 80.0, 5.9, 80.0, 140.0, 33.0, 133.0, 79.0, 168.0, 0, 0, 0, 3, 59, 1, 3, 1, 0, 1 << 18, 59],   # last alien, wave clear
+        [76.0, 18.0, 122.0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 10, 3, 9, 1, 0, 0, -1, 0x7FFFFF, 9999],                           # drop to the bottom
+    ]
+    cases = np.array(cases, np.float64)
+    n = len(cases)
+    g, o = make_pair(oracle, L.ENV_SPACEINVADERS, n, seed=5)
+    reals = cases[:, :13].T.copy()
+    ints = cases[:, 13:].T.astype(np.int64).astype(np.uint32).view(np.int32).copy()
+    g.set_state(reals, ints); o.set_state(reals, ints)
+    assert np.array_equal(g.get_obs(), o.get_obs())
+    for t in range(4):
+        a = np.array([4, 5, 1, 2, 1, 0], np.int32)
+        obs, rew, done, _ = g.step_host(a, want_obs=True)
+        orew, odone, _ = o.step(a)
+        assert np.array_equal(rew.astype(np.float64), orew) and np.array_equal(done, odone), t
+        gr, gi = g.get_state(); orr, oi = o.get_state()
+        assert np.array_equal(bits(gr), bits(orr)) and np.array_equal(gi, oi), t
+        assert np.array_equal(obs, o.get_obs()), t
+
+
 def _breakout_actions(rng, g, n):
     """half the envs act at random (with out-of-range actions), the others fire and follow the ball"""
     reals, ints = g.get_state()
@@ -257,7 +330,7 @@ def test_breakout_win_and_edge_frames(oracle):
     assert np.array_equal(obs, o.get_obs())
 
 
-@pytest.mark.parametrize("env_id", [L.ENV_CARTPOLE, L.ENV_PENDULUM, L.ENV_CLIFFWALKING, L.ENV_PONG, L.ENV_DUMMY, L.ENV_BREAKOUT])
+@pytest.mark.parametrize("env_id", [L.ENV_CARTPOLE, L.ENV_PENDULUM, L.ENV_CLIFFWALKING, L.ENV_PONG, L.ENV_DUMMY, L.ENV_BREAKOUT, L.ENV_SPACEINVADERS])
 @pytest.mark.parametrize("flags,time_limit", [(L.AUTORESET | L.RECORD_STATS, 0), (L.RECORD_STATS, 17), (L.AUTORESET | L.RECORD_STATS, 9), (L.AUTORESET, 0)])
 def test_fused_wrappers(oracle, env_id, flags, time_limit):
     """auto-reset, TimeLimit (Wrappers.TimeLimit.cs) and RecordEpisodeStatistics (EnvWrapper.cs:23-58) fused in the step"""
@@ -265,7 +338,7 @@ def test_fused_wrappers(oracle, env_id, flags, time_limit):
     g, o = make_pair(oracle, env_id, n, seed=13, flags=flags, time_limit=time_limit, base=1 << 33)
     g.reset(); o.reset()
     rng = np.random.default_rng(6)
-    exact = env_id in (L.ENV_CLIFFWALKING, L.ENV_PONG, L.ENV_DUMMY, L.ENV_BREAKOUT)
+    exact = env_id in (L.ENV_CLIFFWALKING, L.ENV_PONG, L.ENV_DUMMY, L.ENV_BREAKOUT, L.ENV_SPACEINVADERS)
     for t in range(steps):
         a = random_actions(rng, env_id, n)
         obs, rew, done, trunc = g.step_host(a, want_trunc=time_limit > 0)
@@ -293,7 +366,7 @@ def test_fused_wrappers(oracle, env_id, flags, time_limit):
             assert gs.min_return == os_.min_return and gs.max_return == os_.max_return
 
 
-@pytest.mark.parametrize("env_id", CLASSIC + [L.ENV_FROZENLAKE, L.ENV_TAXI, L.ENV_PONG, L.ENV_BREAKOUT])
+@pytest.mark.parametrize("env_id", CLASSIC + [L.ENV_FROZENLAKE, L.ENV_TAXI, L.ENV_PONG, L.ENV_BREAKOUT, L.ENV_SPACEINVADERS])
 def test_random_policy_and_rollout(oracle, env_id):
     """actions sampled on the device (Spaces.Discrete.cs:18 / Spaces.Box.cs:25-33) and K fused steps"""
     n, k = 2051, 24
@@ -311,7 +384,7 @@ def test_random_policy_and_rollout(oracle, env_id):
     assert np.array_equal(bits(gr), bits(g2r)) and np.array_equal(gi, g2i)
     s1, s2, so = g.stats(), g2.stats(), o.stats()
     assert s1.episodes == s2.episodes and s1.sum_length == s2.sum_length
-    if env_id in (L.ENV_FROZENLAKE, L.ENV_TAXI, L.ENV_PONG, L.ENV_BREAKOUT):
+    if env_id in (L.ENV_FROZENLAKE, L.ENV_TAXI, L.ENV_PONG, L.ENV_BREAKOUT, L.ENV_SPACEINVADERS):
         assert np.array_equal(bits(gr), bits(orr)) and np.array_equal(gi, oi)
         assert s1.episodes == so.episodes and s1.sum_return == so.sum_return and s1.sum_length == so.sum_length
     else:

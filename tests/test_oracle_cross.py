@@ -194,6 +194,60 @@ def test_breakout_win_and_edge_frames(oracle):
         assert np.array_equal(oracle.breakout_render(*c), NP.breakout_frame(*c)), c
 
 
+def _invaders_action(rng, game, i):
+    """odd envs act at random; even envs hunt: move under the nearest occupied column and fire"""
+    if i & 1:
+        return int(rng.integers(0, 6))
+    cols = [c for c in range(11) if any(game.aliens[r][c] for r in range(5))]
+    if not cols:
+        return 1
+    gun = game.player_x + 4.0
+    target = min((game.form_x + c * 12 + 3.0 for c in cols), key=lambda x: abs(x - gun))
+    return 4 if target > gun + 2 else (5 if target < gun - 2 else 1)
+
+
+def test_invaders_bitwise(oracle):
+    n = 12
+    v = oracle.OracleVec(oracle.SPACEINVADERS, n, seed=SEED)
+    v.reset()
+    games = [NP.InvadersGame() for _ in range(n)]
+    rng = np.random.default_rng(7)
+    shots = waves = 0
+    for t in range(2600):
+        a = np.array([_invaders_action(rng, g, i) for i, g in enumerate(games)], np.int32)
+        rew, done, _ = v.step(a)
+        reals, ints = v.get_state()
+        for i, g in enumerate(games):
+            r2, d2 = g.step(int(a[i]), SEED, i, t + 1)
+            er, ei = g.image()
+            assert np.array_equal(bits(reals[:, i]), bits(er)) and np.array_equal(ints[:, i], ei), (t, i)
+            assert rew[i] == r2 and bool(done[i]) == d2, (t, i)
+            shots += len(g.alien_bullets) > 0
+            waves += r2 >= 100
+        if t % 400 == 399 or t == 30:
+            frames = v.get_obs()
+            for i in range(0, n, 5):
+                assert np.array_equal(frames[i], games[i].frame_bytes()), (t, i)
+    assert shots > 0 and waves > 0            # alien fire and a cleared wave were both exercised
+    assert any(g.lives < 3 for g in games)    # and a cannon was hit
+
+
+def test_invaders_frames_edge_cases(oracle):
+    """sprites clipped at the borders, bullets over sprites, many-digit and negative scores, no lives"""
+    g = NP.InvadersGame()
+    cases = [
+        ([0.0, 10.0, 40.0, 3.9, 0.0, 157.2, 208.9, 80.0, 100.0, 12.0, 42.0, 159.0, 170.5],
+         [123456, 3, 7, 1, 3, 2, -1, 0x7FFFFF, 7]),
+        ([152.0, 27.5, 120.0, 30.0, 121.0, 0, 0, 0, 0, 156.0, 172.0, 0, 0], [-50, 1, 9, 0, 1, 1, 0x55555555, 0x2AAAAA, 9]),
+        ([75.4, -3.0, 161.0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0], [990, 0, 0, 1, 0, 0, -1, 0x7FFFFF, 0]),
+        ([80.0, 150.0, 5.0, 11.0, 11.0, 121.0, 12.0, 100.0, 190.0, 50.0, 189.5, 20.0, 12.0], [2147483647, 13, 5, 1, 3, 2, 1 << 10, 1 << 22, 1]),
+    ]
+    for reals, ints in cases:
+        ints = np.array(ints, np.int64).astype(np.uint32).view(np.int32)
+        g.load(np.array(reals), ints)
+        assert np.array_equal(oracle.invaders_render(reals, ints), g.frame_bytes())
+
+
 def test_wrappers_match_numpy_restatement(oracle):
     """RecordEpisodeStatistics(TimeLimit(CartPole)) without autoreset, stepping past done."""
     n = 64
