@@ -122,6 +122,22 @@ def test_reference_shape_tests_on_device():
     assert frame.dtype == np.uint8 and len(frame) == 210 * 160 * 3
     s, r, d, info = env.Step(2)
     assert -1 <= r <= 1 and set(info) == {"left_score", "right_score", "ball_x", "ball_y"}
+    env = G.Breakout()  # AtariEnvTests.cs:37-62
+    assert env.ActionSpace.N == 4
+    frame = env.Reset()
+    assert frame.dtype == np.uint8 and len(frame) == 210 * 160 * 3
+    s, r, d, info = env.Step(0)
+    assert len(s) == 210 * 160 * 3 and r >= 0
+    assert info == {"score": 0, "lives": 5, "ball_x": 80.0, "ball_y": 180.0, "bricks_remaining": 108}
+    env = G.SpaceInvaders()  # AtariEnvTests.cs:64-90
+    assert env.ActionSpace.N == 6
+    frame = env.Reset()
+    assert frame.dtype == np.uint8 and len(frame) == 210 * 160 * 3
+    s, r, d, info = env.Step(0)
+    assert len(s) == 210 * 160 * 3 and r >= 0
+    assert info == {"score": 0, "lives": 3, "aliens_remaining": 55, "player_x": 76.0}
+    G.RegisterAll()  # GymnasiumRegistration.cs:22-24
+    assert isinstance(G.EnvRegistry.Make("Breakout-v4"), G.Breakout) and isinstance(G.EnvRegistry.Make("SpaceInvaders-v4"), G.SpaceInvaders)
     env = G.DummyEnv()  # DummyEnvTests.cs:6-21
     assert env.Reset() == 0
     s, r, d, _ = env.Step(1)
