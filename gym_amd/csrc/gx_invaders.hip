@@ -1,7 +1,8 @@
 // SpaceInvaders: game state stepped one env per lane in binary64, and the
-// 210x160x3 frame of every env painted by a workgroup into a one-byte-per-
-// pixel palette image in LDS, in the reference's own drawing order, then
-// expanded to RGB with coalesced 12-byte stores.
+// 210x160x3 frame of every env painted by a workgroup into a four-bit-per-
+// pixel palette image in LDS (16.8 KB, so eight workgroups fit a CU), in the
+// reference's own drawing order, then expanded to RGB with coalesced 12-byte
+// stores.
 //
 // The reference keeps its bullets in List<(double,double)>
 // (Envs.SpaceInvaders.cs:35-36).  Player bullets are capped at three by the
@@ -20,7 +21,7 @@ namespace gx {
 
 namespace si {
 constexpr double kPlayerSpeed = 3.0, kBulletSpeed = 6.0, kAlienSpeed = 0.5, kAlienDropSpeed = 8.0;
-constexpr int kPlayerW = 8, kPlayerH = 6, kAlienW = 6, kAlienH = 6, kBulletW = 2, kBulletH = 4;
+constexpr int kPlayerW = 8, kPlayerH = 6, kAlienW = 6, kAlienH = 6;  // bullets are 2 x 4 (eight pixels, see the raster)
 constexpr int kRows = 5, kCols = 11, kMaxPB = 3, kMaxAB = 2;
 constexpr uint64_t kAllAliens = (1ull << (kRows * kCols)) - 1ull;
 
@@ -290,29 +291,36 @@ __global__ void __launch_bounds__(kBlock) invaders_sample_kernel(StepArgs a, int
 }
 
 // palette of the frame: index -> r | g << 8 | b << 16
-enum : uint8_t { kBlack = 0, kMagenta, kCyan, kYellow, kGreen, kRed, kWhite };
+enum : uint32_t { kBlack = 0, kMagenta, kCyan, kYellow, kGreen, kRed, kWhite };
 __device__ __forceinline__ uint32_t palette(uint32_t idx) {
   // Envs.SpaceInvaders.cs:374-378 alien rows, :393 yellow, :399 red, :455 and :409 green, :521 white
   return idx == kMagenta ? 0xFF00FFu : idx == kCyan ? 0xFFFF00u : idx == kYellow ? 0x00FFFFu : idx == kGreen ? 0x00FF00u :
          idx == kRed ? 0x0000FFu : idx == kWhite ? 0xFFFFFFu : 0u;
 }
 
-// the reference's DrawRectangle bounds check (Envs.SpaceInvaders.cs:461-478) for one pixel
-__device__ __forceinline__ void put(uint8_t* img, int px, int py, uint8_t c) {
-  if (px >= 0 && px < kScreenW && py >= 0 && py < kScreenH) img[py * kScreenW + px] = c;
+// One pixel of the palette image (eight 4-bit pixels per word) with the reference's
+// DrawRectangle bounds check (Envs.SpaceInvaders.cs:461-478).  Clear-then-set with two LDS
+// atomics: lanes painting other pixels of the same word do not interfere, and lanes painting
+// the same pixel within a layer write the same colour, so the last clear is always followed
+// by a set of that colour.
+__device__ __forceinline__ void put(uint32_t* img, int px, int py, uint32_t c) {
+  if (px >= 0 && px < kScreenW && py >= 0 && py < kScreenH) {
+    const int idx = py * kScreenW + px, sh = (idx & 7) * 4;
+    atomicAnd(&img[idx >> 3], ~(0xFu << sh));
+    atomicOr(&img[idx >> 3], c << sh);
+  }
 }
 
 // One workgroup per env.  Layers are painted in the source's order with a barrier between
-// layers of different colour; within a layer every pixel receives one colour, so concurrent
-// byte stores need no ordering.
+// layers of different colour; within a layer every pixel receives one colour.
 __global__ void __launch_bounds__(kBlock) invaders_raster_kernel(StepArgs a, uint8_t* __restrict__ frames) {
-  __shared__ uint32_t img_words[kScreenW * kScreenH / 4];
-  uint8_t* img = reinterpret_cast<uint8_t*>(img_words);
+  constexpr int kImgWords = kScreenW * kScreenH / 8;
+  __shared__ uint32_t img[kImgWords];
   const uint64_t env = blockIdx.x;
   const int tid = threadIdx.x;
   const double* r = static_cast<const double*>(a.state_real);
   const int32_t* n = a.state_int;
-  for (int w = tid; w < kScreenW * kScreenH / 4; w += kBlock) img_words[w] = 0;
+  for (int w = tid; w < kImgWords; w += kBlock) img[w] = 0;
   __syncthreads();
 
   // aliens: 55 x 36 sprite cells, Envs.SpaceInvaders.cs:361-385, 413-435
@@ -328,7 +336,7 @@ __global__ void __launch_bounds__(kBlock) invaders_raster_kernel(StepArgs a, uin
       const uint32_t bits = dy < 5 ? (sprite >> (6 * dy)) & 0x3Fu : last_row;
       if (((aliens >> cell) & 1ull) && ((bits >> dx) & 1u)) {
         const int x = (int)(formX + col * 12), y = (int)(formY + row * 10);  // (int) truncates toward zero
-        put(img, x + dx, y + dy, (uint8_t)(kMagenta + row));  // magenta, cyan, yellow, green, red
+        put(img, x + dx, y + dy, (uint32_t)(kMagenta + row));  // magenta, cyan, yellow, green, red
       }
     }
   }
@@ -363,7 +371,7 @@ __global__ void __launch_bounds__(kBlock) invaders_raster_kernel(StepArgs a, uin
     __syncthreads();
     for (int c = tid; c < 5 * kScreenW; c += kBlock) {
       const int dy = c / kScreenW, x = c - dy * kScreenW;
-      if ((digit_rows[dy][x >> 5] >> (x & 31)) & 1u) img[(10 + dy) * kScreenW + x] = kWhite;
+      if ((digit_rows[dy][x >> 5] >> (x & 31)) & 1u) put(img, x, 10 + dy, kWhite);
     }
   }
   __syncthreads();
@@ -379,14 +387,14 @@ __global__ void __launch_bounds__(kBlock) invaders_raster_kernel(StepArgs a, uin
   }
   __syncthreads();
   // ground line, :407-410
-  for (int c = tid; c < 2 * kScreenW; c += kBlock) img[(kScreenH - 20) * kScreenW + c] = kGreen;
+  for (int c = tid; c < 2 * kScreenW / 8; c += kBlock) img[(kScreenH - 20) * kScreenW / 8 + c] = 0x11111111u * kGreen;
   __syncthreads();
 
   uint8_t* frame = frames + env * (uint64_t)kFrameBytes;
   for (int c = tid; c < kGroupsPerFrame; c += kBlock) {
-    const uint32_t w = img_words[c];
+    const uint32_t w = img[c >> 1] >> ((c & 1) * 16);
     *reinterpret_cast<U3*>(frame + (uint64_t)c * 12) =
-        pack_rgb4(palette(w & 0xFFu), palette((w >> 8) & 0xFFu), palette((w >> 16) & 0xFFu), palette(w >> 24));
+        pack_rgb4(palette(w & 0xFu), palette((w >> 4) & 0xFu), palette((w >> 8) & 0xFu), palette((w >> 12) & 0xFu));
   }
 }
 
