@@ -775,14 +775,18 @@ extern "C" int gx_vec_step_async(gx_vec* v, const void* h_actions, void* h_obs, 
   return GX_OK;
 }
 
+// Only Acrobot has actions the reference throws on (Envs.Acrobot.cs:45,51); the host path
+// validates them before launch, so the device flag matters for the zero-copy path alone.
+static bool has_error_flag(const gx_vec* v) { return v->desc.env_id == GX_ENV_ACROBOT; }
+
 extern "C" int gx_vec_wait(gx_vec* v) {
   if (!v) return fail(GX_ERR_INVALID, "gx_vec_wait: null batch");
   gx_ctx* c = v->ctx;
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipStreamSynchronize(c->compute));
-  HIP_TRY(hipMemcpyAsync(v->h_error, v->d_error, 4, hipMemcpyDeviceToHost, c->copy));
+  if (has_error_flag(v)) HIP_TRY(hipMemcpyAsync(v->h_error, v->d_error, 4, hipMemcpyDeviceToHost, c->copy));
   HIP_TRY(hipStreamSynchronize(c->copy));
-  if (*v->h_error) {
+  if (has_error_flag(v) && *v->h_error) {
     *v->h_error = 0;
     HIP_TRY(hipMemsetAsync(v->d_error, 0, 4, c->copy));
     HIP_TRY(hipStreamSynchronize(c->copy));
