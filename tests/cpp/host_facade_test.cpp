@@ -1,0 +1,191 @@
+// Exercises include/gymx.hpp (the C++ host facade over the C ABI) on a GPU:
+// the reference's own unit tests restated (Gymnasium.Tests/*.cs), the
+// VectorEnv contract, the fused and the host-composed wrappers, and a replay
+// of a CartPole batch against the CPU oracle (linked here as the checker).
+// Prints one line per check; exit status 0 when all pass.
+// Built by tests/cpp/facade_build.py.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "gymx.hpp"
+#include "oracle/gym_oracle.h"
+
+static int failures = 0;
+#define CHECK(cond)                                                      \
+  do {                                                                   \
+    if (!(cond)) {                                                       \
+      std::printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #cond);        \
+      failures++;                                                        \
+    }                                                                    \
+  } while (0)
+
+using namespace gymx;
+
+static void reference_unit_tests() {
+  {  // CartPoleTests.cs:8-19
+    DeviceEnv<CartPole> env;
+    auto s = env.Reset();
+    CHECK(s.size() == 4);
+    for (int i = 0; i < 10; i++) {
+      auto r = env.Step(1);
+      CHECK(r.reward >= 0 && r.reward <= 1);
+    }
+    CHECK(env.ActionSpace.N == 2 && env.ObservationSpace.Dimension() == 4);
+  }
+  {  // AcrobotTests.cs:7-18, and the IndexOutOfRangeException of Envs.Acrobot.cs:51
+    DeviceEnv<Acrobot> env;
+    CHECK(env.Reset().size() == 6);
+    CHECK(env.Step(1).reward <= 0);
+    bool threw = false;
+    try { env.Step(3); } catch (const std::out_of_range&) { threw = true; }
+    CHECK(threw);
+  }
+  {  // MountainCarTests.cs:7-19, MountainCarContinuousTests.cs:7-19, PendulumTests.cs:7-18
+    DeviceEnv<MountainCar> mc;
+    auto s = mc.Reset();
+    CHECK(mc.ObservationSpace.Contains({s[0], s[1]}));
+    CHECK(mc.Step(2).reward <= 0);
+    DeviceEnv<MountainCarContinuous> mcc;
+    auto t = mcc.Reset();
+    CHECK(mcc.ObservationSpace.Contains({t[0], t[1]}));
+    mcc.Step(0.5f);
+    DeviceEnv<Pendulum> p;
+    CHECK(p.Reset().size() == 3 && p.Step(0.0f).reward <= 0);
+  }
+  {  // AtariEnvTests.cs:9-91
+    DeviceEnv<Pong> pong;
+    CHECK(pong.ActionSpace.N == 4 && pong.Reset().size() == 210 * 160 * 3);
+    auto r = pong.Step(0);
+    CHECK(r.state.size() == 210 * 160 * 3 && r.reward >= -1 && r.reward <= 1 && r.info.count("left_score") == 1);
+    DeviceEnv<Breakout> bk;
+    CHECK(bk.ActionSpace.N == 4 && bk.Reset().size() == 210 * 160 * 3);
+    auto b = bk.Step(0);
+    CHECK(b.reward >= 0 && b.info.at("lives") == 5 && b.info.at("bricks_remaining") == 108);
+    DeviceEnv<SpaceInvaders> si;
+    CHECK(si.ActionSpace.N == 6 && si.Reset().size() == 210 * 160 * 3);
+    auto v = si.Step(0);
+    CHECK(v.reward >= 0 && v.info.at("lives") == 3 && v.info.at("aliens_remaining") == 55 && v.info.at("player_x") == 76.0);
+  }
+  {  // DummyEnvTests.cs:6-21
+    DeviceEnv<DummyEnv> env;
+    CHECK(env.Reset() == 0);
+    auto r = env.Step(1);
+    CHECK(r.state == 1 && r.reward == 1.0 && !r.done);
+    for (int i = 0; i < 9; i++) r = env.Step(1);
+    CHECK(r.done);
+  }
+  std::printf("reference unit tests restated: done\n");
+}
+
+static void registry_and_spaces() {
+  GymnasiumRegistration::RegisterAll();  // GymnasiumRegistration.cs:8-30
+  CHECK(EnvRegistry::List().size() == 11);
+  auto env = EnvRegistry::Make<DeviceEnv<CartPole>>("CartPole-v1");
+  CHECK(env->Reset().size() == 4);
+  bool threw = false;
+  try { EnvRegistry::Make("LunarLander-v2"); } catch (const std::invalid_argument&) { threw = true; }  // EnvRegistry.cs:28-31
+  CHECK(threw);
+  Box box({-1.0f, 0.0f}, {1.0f, 2.0f});
+  for (int i = 0; i < 100; i++) CHECK(box.Contains(box.Sample()));
+  CHECK(!box.Contains({2.0f, 1.0f}) && !box.Contains({0.0f}));
+  threw = false;
+  try { Box bad({0.0f}, {1.0f, 2.0f}); } catch (const std::invalid_argument&) { threw = true; }  // Spaces.Box.cs:18-19
+  CHECK(threw);
+  Discrete d(5);
+  for (int i = 0; i < 100; i++) CHECK(d.Contains(d.Sample()));
+  CHECK(!d.Contains(5) && !d.Contains(-1) && d.Shape() == std::vector<int>{1});
+  std::printf("registry and spaces: done\n");
+}
+
+// VectorEnv over 1000 CartPoles replayed against the oracle: same seed, same actions.
+static void vector_env_against_oracle() {
+  const uint64_t n = 1000;
+  BatchOptions o;
+  o.seed = 42;
+  o.autoreset = true;
+  o.record_stats = true;
+  VectorEnv<CartPole> vec(n, o);
+  gxo_vec* ref = gxo_vec_create(GXO_CARTPOLE, n, 42, GXO_AUTORESET | GXO_RECORD_STATS, 0, nullptr, 0);
+  auto states = vec.Reset();
+  gxo_vec_reset(ref);
+  CHECK(states.size() == n && vec.NumEnvs() == n);
+  std::vector<float> want(4 * n);
+  gxo_vec_get_obs(ref, want.data());
+  bool same = true;
+  for (uint64_t i = 0; i < n; i++)
+    for (int c = 0; c < 4; c++) same = same && std::memcmp(&states[i][c], &want[c * n + i], 4) == 0;
+  CHECK(same);
+  std::vector<int> actions(n);
+  std::vector<double> reward(n);
+  std::vector<uint8_t> done(n), trunc(n);
+  uint64_t x = 88172645463325252ull;
+  for (int t = 0; t < 60; t++) {
+    for (uint64_t i = 0; i < n; i++) {
+      x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+      actions[i] = (int)(x & 1);
+    }
+    auto res = vec.Step(actions);
+    std::vector<int32_t> a32(actions.begin(), actions.end());
+    gxo_vec_step(ref, a32.data(), reward.data(), done.data(), trunc.data());
+    gxo_vec_get_obs(ref, want.data());
+    for (uint64_t i = 0; i < n; i++) {
+      same = same && res[i].reward == reward[i] && res[i].done == (done[i] != 0);
+      for (int c = 0; c < 4; c++) same = same && std::memcmp(&res[i].state[c], &want[c * n + i], 4) == 0;
+    }
+  }
+  CHECK(same);
+  gx_stats gs = vec.Device().Stats();
+  gxo_stats os;
+  gxo_vec_stats(ref, &os);
+  CHECK(gs.episodes == os.episodes && gs.episodes > 0 && gs.sum_return == os.sum_return && gs.sum_length == os.sum_length);
+  gxo_vec_destroy(ref);
+  bool threw = false;
+  try { vec.Step(std::vector<int>(n - 1)); } catch (const std::invalid_argument&) { threw = true; }
+  CHECK(threw);
+  std::printf("VectorEnv<CartPole> x 1000, 60 steps: bit-identical to the oracle, %lld episodes\n", (long long)gs.episodes);
+}
+
+// TimeLimit and RecordEpisodeStatistics: host-composed around one env (Wrappers.TimeLimit.cs,
+// EnvWrapper.cs:23-58) and fused into the batch give the same episodes.
+static void wrappers() {
+  auto inner = std::make_shared<DeviceEnv<DummyEnv>>();
+  auto limited = std::make_shared<TimeLimit<int, int>>(inner, 4);
+  RecordEpisodeStatistics<int, int> rec(limited);
+  rec.Reset();
+  StepResult<int> r{};
+  for (int i = 0; i < 4; i++) r = rec.Step(1);
+  CHECK(r.done && r.info.count("TimeLimit.truncated") == 1);
+  CHECK(rec.EpisodeRewards.size() == 1 && rec.EpisodeRewards[0] == 1 + 2 + 3 + 4 && rec.EpisodeLengths[0] == 4);
+  rec.Step(1);
+  rec.Reset();  // EnvWrapper.cs:34-38: the open episode is recorded by Reset()
+  CHECK(rec.EpisodeRewards.size() == 2 && rec.EpisodeLengths[1] == 1);
+
+  BatchOptions o;
+  o.time_limit = 4;
+  o.record_stats = true;
+  VectorEnv<DummyEnv> vec(3, o);
+  vec.Reset();
+  std::vector<StepResult<int>> res;
+  for (int i = 0; i < 4; i++) res = vec.Step({1, 1, 2});
+  CHECK(res[0].done && res[0].info.count("TimeLimit.truncated") == 1 && res[2].state == 8);
+  gx_stats s = vec.Device().Stats();
+  CHECK(s.episodes == 3 && s.sum_length == 12 && s.sum_return == 10 + 10 + 20);
+  std::printf("wrappers, host-composed and fused: done\n");
+}
+
+int main() {
+  int count = 0;
+  if (gx_device_count(&count) != GX_OK || count == 0) {
+    // no GPU: the facade must fail loudly, not fall back
+    bool threw = false;
+    try { Context c(0); } catch (const std::exception& e) { threw = true; std::printf("no GPU: %s\n", e.what()); }
+    return threw ? 77 : 1;
+  }
+  reference_unit_tests();
+  registry_and_spaces();
+  vector_env_against_oracle();
+  wrappers();
+  std::printf(failures ? "FAILED (%d)\n" : "ALL OK\n", failures);
+  return failures ? 1 : 0;
+}
