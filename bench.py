@@ -164,16 +164,19 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl is RCCL on ROCm; gloo only to rehearse several ranks on one GPU")
     ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses GPU local_rank %% device_count")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal: initialise torch.distributed even for one rank (exercises the RCCL barrier / all-reduce path)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist_mod
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if args.share_device:
             local_rank %= torch.cuda.device_count()
         torch.cuda.set_device(local_rank)

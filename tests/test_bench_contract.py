@@ -1,0 +1,44 @@
+"""bench.py prints one JSON line with the agreed fields (small sizes; the real run uses the defaults)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "1"] + list(args),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_default_workload_line():
+    j = _run("--num-envs", "262144", "--no-extra")
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in j, key
+    assert j["metric"] == "env-steps/sec" and j["n_gpus"] == 1 and j["steps"] == 5 and j["warmup"] == 1
+    assert j["higher_is_better"] is True and j["scaling"] == "weak" and j["vs_baseline"] is None and j["data"] == "synthetic"
+    assert "workload" in j["config"] and "model" not in j["config"]
+    roof = j["roofline"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12 and roof["bytes_per_env_step"] == 49
+    # value and the kernel time describe the same run
+    assert abs(j["value"] - 262144 * 5 / (j["ms_per_step"] * 5e-3)) / j["value"] < 1e-6
+    cpu = j["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["value"] > 0 and "sample" in cpu
+    assert j["cpu_baseline_all_cores"]["cores"] >= 1
+
+
+@pytest.mark.gpu
+def test_rollout_workload_line():
+    j = _run("--env", "acrobot", "--rk4", "--rollout", "8", "--num-envs", "65536", "--no-cpu-baseline")
+    assert j["dtype"] == "f64" and j["roofline"]["bound"] == "fp64-valu" and j["roofline"]["unit"] == "TFLOP/s"
+    assert abs(j["value"] - 65536 * 8 * 5 / (j["ms_per_step"] * 5e-3)) / j["value"] < 1e-6
