@@ -68,8 +68,8 @@ struct CartPole {
     Trig<MODE, BOUNDED>::sincos_quarter(theta, sintheta, costheta);
 
     float temp = div_total_mass(force + polemass_length * thetaDot * thetaDot * sintheta);
-    float thetaacc = (gravity * sintheta - costheta * temp) /
-                     (length * (4.0f / 3.0f - div_total_mass(masspole * costheta * costheta)));
+    float thetaacc = divide<MODE>(gravity * sintheta - costheta * temp,
+                                  length * (4.0f / 3.0f - div_total_mass(masspole * costheta * costheta)));
     float xacc = temp - div_total_mass(polemass_length * thetaacc * costheta);
 
     x += tau * xDot;
@@ -296,9 +296,9 @@ struct Acrobot {
                  2 * LINK_MASS_2 * LINK_LENGTH_1 * LINK_COM_POS_2 * dtheta2 * dtheta1 * sin2 +
                  (LINK_MASS_1 * LINK_COM_POS_1 + LINK_MASS_2 * LINK_LENGTH_1) * g * T::cos_minus_half_pi(theta1) +
                  phi2;
-    float ddtheta2 = (u + d2 / d1 * phi1 - LINK_MASS_2 * LINK_LENGTH_1 * LINK_COM_POS_2 * dtheta1 * dtheta1 * sin2 - phi2) /
-                     (LINK_MASS_2 * LINK_COM_POS_2 * LINK_COM_POS_2 + LINK_MOI_2 - d2 * d2 / d1);
-    float ddtheta1 = -(d2 * ddtheta2 + phi1) / d1;
+    float ddtheta2 = divide<MODE>(u + divide<MODE>(d2, d1) * phi1 - LINK_MASS_2 * LINK_LENGTH_1 * LINK_COM_POS_2 * dtheta1 * dtheta1 * sin2 - phi2,
+                                  LINK_MASS_2 * LINK_COM_POS_2 * LINK_COM_POS_2 + LINK_MOI_2 - divide<MODE>(d2 * d2, d1));
+    float ddtheta1 = divide<MODE>(-(d2 * ddtheta2 + phi1), d1);
 
     dtheta1 += dt * ddtheta1;
     dtheta2 += dt * ddtheta2;
@@ -323,7 +323,7 @@ struct Acrobot {
       above = tip_approx > 1.0f;
       if (fabsf(tip_approx - 1.0f) < 1e-5f) above = -LINK_LENGTH_1 * c1n - LINK_LENGTH_2 * T::cos(theta1 + theta2) > 1.0f;
     } else {
-      above = -LINK_LENGTH_1 * c1n - LINK_LENGTH_2 * T::cos(theta1 + theta2) > 1.0f;
+      above = -c1n - (c1n * c2n - s1n * s2n) > 1.0f;  // cos(theta1 + theta2) by the addition formula
     }
     done = above || steps >= 500;
     reward = done ? 0.0f : -1.0f;

@@ -133,6 +133,59 @@ GX_HD void sincos_reduced(double x, double& s, double& c) {
   quadrant((int)fn, sn, cs, s, c);
 }
 
+// ---- binary32 routines of the FAST32 mode (held to 1e-5 relative, not to the last bit) ----
+
+// sin(x) and cos(x) in binary32 for |x| up to a few thousand, absolute error about 1e-7:
+// Cody-Waite reduction against pi/2 in three parts (the first has 8 significant bits, so
+// n * P1 is exact), degree-7 / degree-8 minimax kernels on [-pi/4, pi/4], the quadrant.
+GX_HD void sincosf_bounded(float x, float& s, float& c) {
+  const float P1 = 1.5703125f, P2 = 4.837512969970703125e-4f, P3 = 7.54978995489188216e-8f;
+  const float fn = rintf(x * 0.636619772367581343f);
+  float r = fmaf(-fn, P1, x);
+  r = fmaf(-fn, P2, r);
+  r = fmaf(-fn, P3, r);
+  const float z = r * r;
+  float ps = fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+  ps = fmaf(z, ps, -1.6666654611e-1f);
+  const float sn = fmaf(z * r, ps, r);
+  float pc = fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+  pc = fmaf(z, pc, 4.166664568298827e-2f);
+  const float cs = fmaf(z * z, pc, fmaf(-0.5f, z, 1.0f));
+  const int q = (int)fn;
+  const float a = (q & 1) ? cs : sn;
+  const float b = (q & 1) ? sn : cs;
+  s = (q & 2) ? -a : a;
+  c = ((q + 1) & 2) ? -b : b;
+}
+
+GX_HD float fast_rcpf(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_rcpf(x);
+#else
+  return 1.0f / x;
+#endif
+}
+
+// atan2(y, x) in binary32 for finite arguments, absolute error about 2e-7: the smaller
+// magnitude over the larger, one more reduction at tan(pi/8), a four-term odd kernel, then
+// the octant, the half-plane and the sign of y.  atan2(0, 0) = 0 with the sign of y.
+GX_HD float atan2f_fast(float y, float x) {
+  const float ax = fabsf(x), ay = fabsf(y);
+  const float mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+  float q = mx > 0.0f ? mn * fast_rcpf(mx) : 0.0f;
+  const bool big = q > 0.4142135623730950f;
+  q = big ? (q - 1.0f) * fast_rcpf(q + 1.0f) : q;
+  const float z = q * q;
+  float p = fmaf(z, 8.05374449538e-2f, -1.38776856032e-1f);
+  p = fmaf(z, p, 1.99777106478e-1f);
+  p = fmaf(z, p, -3.33329491539e-1f);
+  float a = fmaf(p * z, q, q);
+  a = big ? a + 0.785398163397448310f : a;
+  a = ay > ax ? 1.570796326794896619f - a : a;
+  a = __builtin_signbit(x) ? 3.141592653589793238f - a : a;  // also for x = -0, like atan2
+  return copysignf(a, y);
+}
+
 // x / 1.1f in binary32, correctly rounded, without a hardware divide: with
 // y = RN(1 / c), q = RN(x y) is within an ulp of x / c, r = x - q c is exact in
 // one fma, and RN(q + r y) is the correctly rounded quotient (Markstein) as

@@ -79,8 +79,8 @@ struct Trig<GX_MODE_EXACT, true> {
   static __device__ __forceinline__ float atan2(float y, float x) { return (float)::atan2((double)y, (double)x); }
 };
 
-template <bool BOUNDED>
-struct Trig<GX_MODE_FAST32, BOUNDED> {
+template <>
+struct Trig<GX_MODE_FAST32, false> {
   static __device__ __forceinline__ void sincos_quarter(float x, float& s, float& c) { ::sincosf(x, &s, &c); }
   static __device__ __forceinline__ void sincos(float x, float& s, float& c) { ::sincosf(x, &s, &c); }
   static __device__ __forceinline__ float cos(float x) { return ::cosf(x); }
@@ -88,6 +88,37 @@ struct Trig<GX_MODE_FAST32, BOUNDED> {
   static __device__ __forceinline__ float sin_plus_pi(float x) { return -::sinf(x); }
   static __device__ __forceinline__ float atan2(float y, float x) { return ::atan2f(y, x); }
 };
+
+// bounded arguments: the library's full-range reduction (its large-argument path alone is
+// several hundred instructions, evaluated branch-free) gives way to the routines of gx_math.h
+template <>
+struct Trig<GX_MODE_FAST32, true> {
+  static __device__ __forceinline__ void sincos_quarter(float x, float& s, float& c) { math::sincosf_bounded(x, s, c); }
+  static __device__ __forceinline__ void sincos(float x, float& s, float& c) { math::sincosf_bounded(x, s, c); }
+  static __device__ __forceinline__ float cos(float x) {
+    float s, c;
+    math::sincosf_bounded(x, s, c);
+    return c;
+  }
+  static __device__ __forceinline__ float cos_minus_half_pi(float x) {
+    float s, c;
+    math::sincosf_bounded(x, s, c);
+    return s;
+  }
+  static __device__ __forceinline__ float sin_plus_pi(float x) {
+    float s, c;
+    math::sincosf_bounded(x, s, c);
+    return -s;
+  }
+  static __device__ __forceinline__ float atan2(float y, float x) { return math::atan2f_fast(y, x); }
+};
+
+// a / b: the IEEE quotient in EXACT mode, a times the hardware reciprocal (about 1.5 ulp) in FAST32
+template <int MODE>
+__device__ __forceinline__ float divide(float a, float b) {
+  if (MODE == GX_MODE_EXACT) return a / b;
+  return a * __builtin_amdgcn_rcpf(b);
+}
 
 // Math.Clamp(float, float, float)
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }

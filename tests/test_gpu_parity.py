@@ -421,6 +421,28 @@ def test_fused_statistics_survive_set_state(oracle, env_id):
     assert gs.min_return == os_.min_return and gs.max_return == os_.max_return
 
 
+@pytest.mark.parametrize("env_id", [L.ENV_CARTPOLE, L.ENV_MOUNTAINCAR])
+def test_fast32_mode_with_autoreset(oracle, env_id):
+    """FAST32 with auto-reset takes the bounded-argument binary32 routines; envs whose done flag ever differs from
+    the oracle's (a state within 1e-7 of a threshold) are left out from then on, there may be only a handful.
+    The run is free (set_state would switch the bounded routines off for a step), so the 1e-5 bounds the error
+    accumulated since an env's last reset, over a dozen steps"""
+    n = 8192
+    g, o = make_pair(oracle, env_id, n, seed=33, mode=L.MODE_FAST32, flags=L.AUTORESET)
+    g.reset(); o.reset()
+    rng = np.random.default_rng(env_id)
+    ok = np.ones(n, bool)
+    for t in range(12):
+        a = random_actions(rng, env_id, n)
+        _, _, done, _ = g.step_host(a)
+        _, odone, _ = o.step(a)
+        ok &= done == odone
+        gr, _ = g.get_state(); orr, _ = o.get_state()
+        err = np.abs(gr.astype(np.float64) - orr) / np.maximum(np.abs(orr), 1e-1)
+        assert err[:, ok].max() <= 1e-5, (t, err[:, ok].max())
+    assert ok.sum() >= n - 8
+
+
 def test_acrobot_invalid_action_is_an_error(oracle):
     """Envs.Acrobot.cs:45,51 throws IndexOutOfRangeException; the ABI returns GX_ERR_INVALID"""
     from gym_amd._lib import GymxError
