@@ -46,11 +46,13 @@ B_ALG = {
     "frozenlake": 4 + 4 + 4 + 4 + 4 + 4 + 1,               # 25 (every non-terminal move pays 0)
     # the others also read and write ep_return
     "pendulum": 12 + 12 + 4 + 4 + 4 + 8 + 8 + 8 + 1,       # 61: reward and ep_return are binary64
+    "mountaincarcontinuous": 8 + 8 + 4 + 4 + 4 + 8 + 8 + 8 + 1,  # 53: likewise
     "pong": 60 + 60 + 4 + 4 + 4 + 4 + 1 + 100800,          # 100937
     "breakout": 72 + 72 + 4 + 4 + 4 + 4 + 1 + 100800,      # 100961
     "spaceinvaders": 140 + 140 + 4 + 4 + 4 + 4 + 1 + 100800,  # 101097
 }
 ENV_IDS = {"cartpole": L.ENV_CARTPOLE, "mountaincar": L.ENV_MOUNTAINCAR, "acrobot": L.ENV_ACROBOT,
+           "mountaincarcontinuous": L.ENV_MOUNTAINCAR_CONT,
            "pendulum": L.ENV_PENDULUM, "frozenlake": L.ENV_FROZENLAKE, "pong": L.ENV_PONG, "breakout": L.ENV_BREAKOUT,
            "spaceinvaders": L.ENV_SPACEINVADERS}
 FRAME_ENVS = ("pong", "breakout", "spaceinvaders")
@@ -99,7 +101,7 @@ def cpu_baseline(env_name, target_seconds=12.0):
     from oracle import oracle as O
 
     eid = {"cartpole": O.CARTPOLE, "acrobot": O.ACROBOT, "mountaincar": O.MOUNTAINCAR, "pendulum": O.PENDULUM,
-           "frozenlake": O.FROZENLAKE, "pong": O.PONG, "breakout": O.BREAKOUT, "spaceinvaders": O.SPACEINVADERS}[env_name]
+           "mountaincarcontinuous": O.MOUNTAINCAR_CONT, "frozenlake": O.FROZENLAKE, "pong": O.PONG, "breakout": O.BREAKOUT, "spaceinvaders": O.SPACEINVADERS}[env_name]
     n = 1024 if env_name in FRAME_ENVS else 1 << 16
     secs, steps_done = O.bench_reference_shaped(eid, n, 8 if env_name in FRAME_ENVS else 16)
     rate = steps_done / max(secs, 1e-9)
@@ -120,7 +122,7 @@ def cpu_baseline_all_cores(env_name, target_seconds=5.0):
     if env_name == "frozenlake":
         return None
     eid = {"cartpole": O.CARTPOLE, "acrobot": O.ACROBOT, "mountaincar": O.MOUNTAINCAR, "pendulum": O.PENDULUM,
-           "pong": O.PONG, "breakout": O.BREAKOUT, "spaceinvaders": O.SPACEINVADERS}[env_name]
+           "mountaincarcontinuous": O.MOUNTAINCAR_CONT, "pong": O.PONG, "breakout": O.BREAKOUT, "spaceinvaders": O.SPACEINVADERS}[env_name]
     cores = max(1, min(16, len(os.sched_getaffinity(0))))
     n = 1 << 18
     secs, steps_done = O.bench_flat_threads(eid, n, 4, cores)

@@ -10,7 +10,7 @@ def run(args):
             j["roofline"].get("bytes_per_env_step", 0))
     except Exception:
         return r.stderr[-300:]
-for env, n in [("cartpole", 1 << 24), ("mountaincar", 1 << 24), ("pendulum", 1 << 24), ("acrobot", 1 << 24), ("frozenlake", 1 << 26), ("pong", 65536), ("breakout", 65536)]:
+for env, n in [("cartpole", 1 << 24), ("mountaincar", 1 << 24), ("mountaincarcontinuous", 1 << 24), ("pendulum", 1 << 24), ("acrobot", 1 << 24), ("frozenlake", 1 << 26), ("pong", 65536), ("breakout", 65536), ("spaceinvaders", 65536)]:
     for pol in ("device", "random"):
         print(env, n, pol, run(["--env", env, "--num-envs", str(n), "--policy", pol]), flush=True)
 print("cartpole fast32", run(["--mode", "fast32"]), flush=True)
