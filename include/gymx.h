@@ -225,7 +225,10 @@ int gx_vec_rollout(gx_vec* vec, int k_steps, int policy, const void* d_actions, 
 int gx_vec_sample_actions(gx_vec* vec, uint64_t tick, void* d_actions, void* stream);
 int gx_vec_tick(const gx_vec* vec, uint64_t* tick);
 
-/* RecordEpisodeStatistics aggregate of this batch (device reduction + copy). */
+/* RecordEpisodeStatistics aggregate of this batch (device reduction + copy).  Runs on the
+ * context's stream: steps enqueued on a caller's own stream must have been synchronised (or
+ * ordered before the context's stream) by the caller.  The same holds for gx_vec_get_state,
+ * gx_vec_get_obs and gx_vec_reset. */
 int gx_vec_stats(gx_vec* vec, gx_stats* out);
 
 /* ---- multi-GPU: episode statistics only -------------------------------- */
