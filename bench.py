@@ -44,6 +44,7 @@ B_ALG = {
     "mountaincar": 8 + 8 + 4 + 4 + 4 + 4 + 1,              # 33
     "acrobot": 24 + 24 + 4 + 4 + 4 + 4 + 1,                # 65
     "frozenlake": 4 + 4 + 4 + 4 + 4 + 4 + 1,               # 25 (every non-terminal move pays 0)
+    "taxi": 4 + 4 + 4 + 4 + 4 + 4 + 1,                     # 25 for the reference's stub; --taxi-full adds ep_return r+w
     # the others also read and write ep_return
     "pendulum": 12 + 12 + 4 + 4 + 4 + 8 + 8 + 8 + 1,       # 61: reward and ep_return are binary64
     "mountaincarcontinuous": 8 + 8 + 4 + 4 + 4 + 8 + 8 + 8 + 1,  # 53: likewise
@@ -52,7 +53,7 @@ B_ALG = {
     "spaceinvaders": 140 + 140 + 4 + 4 + 4 + 4 + 1 + 100800,  # 101097
 }
 ENV_IDS = {"cartpole": L.ENV_CARTPOLE, "mountaincar": L.ENV_MOUNTAINCAR, "acrobot": L.ENV_ACROBOT,
-           "mountaincarcontinuous": L.ENV_MOUNTAINCAR_CONT,
+           "mountaincarcontinuous": L.ENV_MOUNTAINCAR_CONT, "taxi": L.ENV_TAXI,
            "pendulum": L.ENV_PENDULUM, "frozenlake": L.ENV_FROZENLAKE, "pong": L.ENV_PONG, "breakout": L.ENV_BREAKOUT,
            "spaceinvaders": L.ENV_SPACEINVADERS}
 FRAME_ENVS = ("pong", "breakout", "spaceinvaders")
@@ -101,7 +102,7 @@ def cpu_baseline(env_name, target_seconds=12.0):
     from oracle import oracle as O
 
     eid = {"cartpole": O.CARTPOLE, "acrobot": O.ACROBOT, "mountaincar": O.MOUNTAINCAR, "pendulum": O.PENDULUM,
-           "mountaincarcontinuous": O.MOUNTAINCAR_CONT, "frozenlake": O.FROZENLAKE, "pong": O.PONG, "breakout": O.BREAKOUT, "spaceinvaders": O.SPACEINVADERS}[env_name]
+           "taxi": O.TAXI, "mountaincarcontinuous": O.MOUNTAINCAR_CONT, "frozenlake": O.FROZENLAKE, "pong": O.PONG, "breakout": O.BREAKOUT, "spaceinvaders": O.SPACEINVADERS}[env_name]
     n = 1024 if env_name in FRAME_ENVS else 1 << 16
     secs, steps_done = O.bench_reference_shaped(eid, n, 8 if env_name in FRAME_ENVS else 16)
     rate = steps_done / max(secs, 1e-9)
@@ -119,7 +120,7 @@ def cpu_baseline_all_cores(env_name, target_seconds=5.0):
     structs, no result lists, one thread per core.  FrozenLake shares a map object and is skipped."""
     from oracle import oracle as O
 
-    if env_name == "frozenlake":
+    if env_name in ("frozenlake", "taxi"):
         return None
     eid = {"cartpole": O.CARTPOLE, "acrobot": O.ACROBOT, "mountaincar": O.MOUNTAINCAR, "pendulum": O.PENDULUM,
            "mountaincarcontinuous": O.MOUNTAINCAR_CONT, "pong": O.PONG, "breakout": O.BREAKOUT, "spaceinvaders": O.SPACEINVADERS}[env_name]
@@ -157,6 +158,9 @@ def main():
     ap.add_argument("--num-envs", type=int, default=0, help="envs per GPU (default 16 Mi; Pong, Breakout 65536)")
     ap.add_argument("--policy", default="device", choices=["device", "random"])
     ap.add_argument("--mode", default="exact", choices=["exact", "fast32"])
+    ap.add_argument("--map", default=None, help="FrozenLake only: '8x8' or rows joined by '/'")
+    ap.add_argument("--slippery", action="store_true", help="FrozenLake only: the is_slippery extension")
+    ap.add_argument("--taxi-full", action="store_true", help="Taxi only: upstream Taxi-v3 dynamics (extension)")
     ap.add_argument("--rk4", action="store_true", help="Acrobot only: the RK4 / binary64 extension (upstream dynamics)")
     ap.add_argument("--rollout", type=int, default=1,
                     help="K > 1: every timed step is one fused K-step rollout launch (state stays in registers, "
@@ -201,6 +205,10 @@ def main():
         if args.env != "acrobot":
             ap.error("--rk4 applies to --env acrobot")
         flags |= L.ACROBOT_RK4
+    if args.slippery:
+        flags |= L.SLIPPERY
+    if args.taxi_full:
+        flags |= L.TAXI_FULL
     k_roll = max(1, args.rollout)
     if k_roll > 1:
         args.policy = "random"
@@ -209,7 +217,7 @@ def main():
     base, n_local = shard(n * world, rank, world)
     assert n_local == n
     batch = DeviceBatch(ctx, ENV_IDS[args.env], n, seed=0x9E3779B97F4A7C15, flags=flags, mode=mode,
-                        env_index_base=base)
+                        env_index_base=base, map_rows=args.map)
     batch.reset()
     stream_ptr = torch.cuda.current_stream().cuda_stream
     view = batch.view()
@@ -237,13 +245,14 @@ def main():
         # f64 state r+w, steps r+w, reward, done, derived f32 observation rows
         b_alg = 32 + 32 + 4 + 4 + 4 + 1 + 24
     else:
-        b_alg = B_ALG[args.env] - (4 if args.policy == "random" else 0)
+        b_alg = B_ALG[args.env] - (4 if args.policy == "random" else 0) + (8 if args.taxi_full else 0)
     achieved = b_alg * n / (kernel_ms * 1e-3) / 1e9
     if k_roll > 1:
         kind = "fused %d-step rollout kernel (one launch per timed step)" % k_roll
     else:
         kind = "single-step kernel"
-    name = args.env + (" RK4/fp64" if args.rk4 else "")
+    name = args.env + (" RK4/fp64" if args.rk4 else "") + (" " + args.map if args.map else "") + \
+        (" slippery" if args.slippery else "") + (" full Taxi-v3" if args.taxi_full else "")
     out = {
         "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
