@@ -158,6 +158,17 @@ __global__ void __launch_bounds__(256) w16_chunk_records(uint8_t* p, const Rec* 
   f[i] = u32x4{acc, acc + 1, acc + 2, acc + 3};
 }
 
+// U: per-frame workgroups with every frame starting on a 4 KiB boundary (pitch 102 400)
+constexpr int kPitch = 102400;
+__global__ void __launch_bounds__(256) w16_per_frame_pitched(uint8_t* p, uint32_t v) {
+  u32x4* f = reinterpret_cast<u32x4*>(p + (uint64_t)blockIdx.x * kPitch);
+  for (int c = threadIdx.x; c < kFrame / 16; c += 256) f[c] = u32x4{v, v, v, v};
+}
+__global__ void __launch_bounds__(256) w12_per_frame_pitched(uint8_t* p, uint32_t v) {
+  uint8_t* f = p + (uint64_t)blockIdx.x * kPitch;
+  for (int c = threadIdx.x; c < kFrame / 12; c += 256) *reinterpret_cast<U3*>(f + (uint64_t)c * 12) = U3{v, v, v};
+}
+
 template <class F>
 static void run(const char* name, F launch) {
   hipEvent_t e0, e1;
@@ -210,6 +221,12 @@ int main() {
   run("T records, work 10", [&] { hipLaunchKernelGGL(w16_chunk_records<10>, dim3((unsigned)((n / 16 + 255) / 256)), dim3(256), 0, 0, p, recs, n / 16); });
   run("T records, work 25", [&] { hipLaunchKernelGGL(w16_chunk_records<25>, dim3((unsigned)((n / 16 + 255) / 256)), dim3(256), 0, 0, p, recs, n / 16); });
   hipFree(recs);
+  uint8_t* pp;
+  if (hipMalloc(&pp, (uint64_t)kPitch * kEnvs) == hipSuccess) {
+    run("U w16 per frame pitched", [&] { hipLaunchKernelGGL(w16_per_frame_pitched, dim3(kEnvs), dim3(256), 0, 0, pp, 1u); });
+    run("U w12 per frame pitched", [&] { hipLaunchKernelGGL(w12_per_frame_pitched, dim3(kEnvs), dim3(256), 0, 0, pp, 1u); });
+    hipFree(pp);
+  }
   hipFree(st);
   hipFree(p);
   return 0;
