@@ -13,6 +13,7 @@
 
 #include "gx_device.h"
 #include "gx_frame.h"
+#include "gx_frame_step.h"
 #include "gx_launch.h"
 
 namespace gx {
@@ -145,66 +146,17 @@ __device__ __forceinline__ void store(const StepArgs& a, uint64_t i, const State
 }
 }  // namespace bk
 
-template <int POLICY>
-__global__ void __launch_bounds__(kBlock) breakout_step_kernel(StepArgs a) {
-  const bool autoreset = (a.flags & GX_AUTORESET) != 0;
-  const bool record = (a.flags & GX_RECORD_STATS) != 0;
-  StatAcc acc;
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < a.num_envs; i += (uint64_t)gridDim.x * kBlock) {
-    bk::State s;
-    bk::load(a, i, s);
-    int32_t ep_ret = 0, ep_len = 0;
-    if (record) {
-      ep_ret = static_cast<const int32_t*>(a.ep_return)[i];
-      if (a.ep_length) ep_len = a.ep_length[i];
-    }
-    const uint64_t env = a.env_index_base + i;
-    float reward = 0.0f;
-    bool done = false, trunc = false;
-    for (int k = 0; k < a.k_steps; k++) {
-      const RngKey key = make_key(a.seed_lo, a.seed_hi, a.tick + (uint64_t)k);
-      int act;
-      if (POLICY == GX_POLICY_RANDOM) act = philox_block(key, env, 2, 0).below(0, 4);  // Discrete(4), Envs.Breakout.cs:44
-      else act = static_cast<const int32_t*>(a.actions)[(uint64_t)k * a.action_stride + i];
-      bk::step(s, act, key, env, reward, done);
-      trunc = a.time_limit > 0 && s.steps >= a.time_limit;  // Wrappers.TimeLimit.cs:26-31
-      done = done || trunc;
-      if (record) {  // EnvWrapper.cs:46-55
-        ep_ret += (int32_t)reward;
-        ep_len += 1;
-        if (done) {
-          acc.add((double)ep_ret, a.ep_length ? ep_len : s.steps);
-          ep_ret = 0;
-          ep_len = 0;
-        }
-      }
-      if (autoreset && done) bk::reset(s);
-    }
-    bk::store(a, i, s);
-    if (record) {
-      static_cast<int32_t*>(a.ep_return)[i] = ep_ret;
-      if (a.ep_length) a.ep_length[i] = ep_len;
-    }
-    static_cast<float*>(a.reward)[i] = reward;
-    a.done[i] = done;
-    if (a.truncated) a.truncated[i] = trunc;
+struct BreakoutGame {
+  using State = bk::State;
+  static constexpr int kActions = 4;  // Discrete(4), Envs.Breakout.cs:44
+  static __device__ __forceinline__ void load(const StepArgs& a, uint64_t i, State& s) { bk::load(a, i, s); }
+  static __device__ __forceinline__ void store(const StepArgs& a, uint64_t i, const State& s) { bk::store(a, i, s); }
+  static __device__ __forceinline__ void reset(State& s, const RngKey&, uint64_t) { bk::reset(s); }
+  static __device__ __forceinline__ void step(State& s, int action, const RngKey& key, uint64_t env, float& reward, bool& done) {
+    bk::step(s, action, key, env, reward, done);
   }
-  if (record) block_commit_stats(acc, a.stat_slots);
-}
-
-__global__ void __launch_bounds__(kBlock) breakout_reset_kernel(StepArgs a) {
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < a.num_envs; i += (uint64_t)gridDim.x * kBlock) {
-    bk::State s;
-    bk::reset(s);
-    bk::store(a, i, s);
-  }
-}
-
-__global__ void __launch_bounds__(kBlock) breakout_sample_kernel(StepArgs a, int32_t* out) {
-  const RngKey key = make_key(a.seed_lo, a.seed_hi, a.tick);
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < a.num_envs; i += (uint64_t)gridDim.x * kBlock)
-    out[i] = philox_block(key, a.env_index_base + i, 2, 0).below(0, 4);
-}
+  static __device__ __forceinline__ int32_t steps(const State& s) { return s.steps; }
+};
 
 // One workgroup per env, one four-pixel group per lane and iteration.
 __global__ void __launch_bounds__(kBlock) breakout_raster_kernel(StepArgs a, uint8_t* __restrict__ frames) {
@@ -264,23 +216,13 @@ __global__ void __launch_bounds__(kBlock) breakout_raster_kernel(StepArgs a, uin
   }
 }
 
-hipError_t launch_breakout_step(const StepArgs& a, int policy, dim3 grid, hipStream_t stream) {
-  if (policy == GX_POLICY_RANDOM) hipLaunchKernelGGL(breakout_step_kernel<GX_POLICY_RANDOM>, grid, dim3(kBlock), 0, stream, a);
-  else hipLaunchKernelGGL(breakout_step_kernel<GX_POLICY_DEVICE_ACTIONS>, grid, dim3(kBlock), 0, stream, a);
-  return hipGetLastError();
-}
-hipError_t launch_breakout_reset(const StepArgs& a, dim3 grid, hipStream_t stream) {
-  hipLaunchKernelGGL(breakout_reset_kernel, grid, dim3(kBlock), 0, stream, a);
-  return hipGetLastError();
-}
+hipError_t launch_breakout_step(const StepArgs& a, int policy, dim3 grid, hipStream_t stream) { return launch_frame_step<BreakoutGame>(a, policy, grid, stream); }
+hipError_t launch_breakout_reset(const StepArgs& a, dim3 grid, hipStream_t stream) { return launch_frame_reset<BreakoutGame>(a, grid, stream); }
 hipError_t launch_breakout_raster(const StepArgs& a, uint8_t* frames, hipStream_t stream) {
   if (a.num_envs == 0) return hipSuccess;
   hipLaunchKernelGGL(breakout_raster_kernel, dim3((unsigned)a.num_envs), dim3(kBlock), 0, stream, a, frames);
   return hipGetLastError();
 }
-hipError_t launch_breakout_sample(const StepArgs& a, void* out, dim3 grid, hipStream_t stream) {
-  hipLaunchKernelGGL(breakout_sample_kernel, grid, dim3(kBlock), 0, stream, a, static_cast<int32_t*>(out));
-  return hipGetLastError();
-}
+hipError_t launch_breakout_sample(const StepArgs& a, void* out, dim3 grid, hipStream_t stream) { return launch_frame_sample<BreakoutGame>(a, out, grid, stream); }
 
 }  // namespace gx

@@ -1,0 +1,96 @@
+// The step / reset / sample kernels shared by the frame games (Pong, Breakout, SpaceInvaders):
+// one env per lane, the game state in registers for K steps, TimeLimit, RecordEpisodeStatistics
+// and auto-reset applied as in the other kernels.  A game supplies
+//   struct G { struct State; static constexpr int kActions;
+//              static void load(const StepArgs&, uint64_t i, State&); static void store(...);
+//              static void reset(State&, const RngKey&, uint64_t env);
+//              static void step(State&, int action, const RngKey&, uint64_t env, float& reward, bool& done);
+//              static int32_t steps(const State&); };
+#pragma once
+
+#include "gx_device.h"
+
+namespace gx {
+
+template <class G, int POLICY>
+__global__ void __launch_bounds__(kBlock) frame_step_kernel(StepArgs a) {
+  const bool autoreset = (a.flags & GX_AUTORESET) != 0;
+  const bool record = (a.flags & GX_RECORD_STATS) != 0;
+  StatAcc acc;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < a.num_envs; i += (uint64_t)gridDim.x * kBlock) {
+    typename G::State s;
+    G::load(a, i, s);
+    int32_t ep_ret = 0, ep_len = 0;
+    if (record) {
+      ep_ret = static_cast<const int32_t*>(a.ep_return)[i];
+      if (a.ep_length) ep_len = a.ep_length[i];
+    }
+    const uint64_t env = a.env_index_base + i;
+    float reward = 0.0f;
+    bool done = false, trunc = false;
+    for (int k = 0; k < a.k_steps; k++) {
+      const RngKey key = make_key(a.seed_lo, a.seed_hi, a.tick + (uint64_t)k);
+      int act;
+      if (POLICY == GX_POLICY_RANDOM) act = philox_block(key, env, 2, 0).below(0, G::kActions);  // Discrete.Sample, Spaces.Discrete.cs:18
+      else act = static_cast<const int32_t*>(a.actions)[(uint64_t)k * a.action_stride + i];
+      G::step(s, act, key, env, reward, done);
+      trunc = a.time_limit > 0 && G::steps(s) >= a.time_limit;  // Wrappers.TimeLimit.cs:26-31
+      done = done || trunc;
+      if (record) {  // EnvWrapper.cs:46-55
+        ep_ret += (int32_t)reward;
+        ep_len += 1;
+        if (done) {
+          acc.add((double)ep_ret, a.ep_length ? ep_len : G::steps(s));
+          ep_ret = 0;
+          ep_len = 0;
+        }
+      }
+      if (autoreset && done) G::reset(s, key, env);
+    }
+    G::store(a, i, s);
+    if (record) {
+      static_cast<int32_t*>(a.ep_return)[i] = ep_ret;
+      if (a.ep_length) a.ep_length[i] = ep_len;
+    }
+    static_cast<float*>(a.reward)[i] = reward;
+    a.done[i] = done;
+    if (a.truncated) a.truncated[i] = trunc;
+  }
+  if (record) block_commit_stats(acc, a.stat_slots);
+}
+
+template <class G>
+__global__ void __launch_bounds__(kBlock) frame_reset_kernel(StepArgs a) {
+  const RngKey key = make_key(a.seed_lo, a.seed_hi, a.tick);
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < a.num_envs; i += (uint64_t)gridDim.x * kBlock) {
+    typename G::State s;
+    G::reset(s, key, a.env_index_base + i);
+    G::store(a, i, s);
+  }
+}
+
+template <class G>
+__global__ void __launch_bounds__(kBlock) frame_sample_kernel(StepArgs a, int32_t* out) {
+  const RngKey key = make_key(a.seed_lo, a.seed_hi, a.tick);
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < a.num_envs; i += (uint64_t)gridDim.x * kBlock)
+    out[i] = philox_block(key, a.env_index_base + i, 2, 0).below(0, G::kActions);
+}
+
+template <class G>
+hipError_t launch_frame_step(const StepArgs& a, int policy, dim3 grid, hipStream_t stream) {
+  if (policy == GX_POLICY_RANDOM) hipLaunchKernelGGL((frame_step_kernel<G, GX_POLICY_RANDOM>), grid, dim3(kBlock), 0, stream, a);
+  else hipLaunchKernelGGL((frame_step_kernel<G, GX_POLICY_DEVICE_ACTIONS>), grid, dim3(kBlock), 0, stream, a);
+  return hipGetLastError();
+}
+template <class G>
+hipError_t launch_frame_reset(const StepArgs& a, dim3 grid, hipStream_t stream) {
+  hipLaunchKernelGGL(frame_reset_kernel<G>, grid, dim3(kBlock), 0, stream, a);
+  return hipGetLastError();
+}
+template <class G>
+hipError_t launch_frame_sample(const StepArgs& a, void* out, dim3 grid, hipStream_t stream) {
+  hipLaunchKernelGGL(frame_sample_kernel<G>, grid, dim3(kBlock), 0, stream, a, static_cast<int32_t*>(out));
+  return hipGetLastError();
+}
+
+}  // namespace gx

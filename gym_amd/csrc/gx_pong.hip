@@ -11,6 +11,7 @@
 
 #include "gx_device.h"
 #include "gx_frame.h"
+#include "gx_frame_step.h"
 #include "gx_launch.h"
 
 namespace gx {
@@ -102,67 +103,17 @@ __device__ __forceinline__ void pong_store(const StepArgs& a, uint64_t i, const 
   a.state_int[i] = p.leftScore; a.state_int[a.stride + i] = p.rightScore; a.state_int[2 * a.stride + i] = p.steps;
 }
 
-template <int POLICY>
-__global__ void __launch_bounds__(kBlock) pong_step_kernel(StepArgs a) {
-  const bool autoreset = (a.flags & GX_AUTORESET) != 0;
-  const bool record = (a.flags & GX_RECORD_STATS) != 0;
-  StatAcc acc;
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < a.num_envs; i += (uint64_t)gridDim.x * kBlock) {
-    PongState p;
-    pong_load(a, i, p);
-    int32_t ep_ret = 0, ep_len = 0;
-    if (record) {
-      ep_ret = static_cast<const int32_t*>(a.ep_return)[i];
-      if (a.ep_length) ep_len = a.ep_length[i];
-    }
-    const uint64_t env = a.env_index_base + i;
-    float reward = 0.0f;
-    bool done = false, trunc = false;
-    for (int k = 0; k < a.k_steps; k++) {
-      const RngKey key = make_key(a.seed_lo, a.seed_hi, a.tick + (uint64_t)k);
-      int act;
-      if (POLICY == GX_POLICY_RANDOM) act = philox_block(key, env, 2, 0).below(0, 4);  // Discrete(4), Envs.Pong.cs:36
-      else act = static_cast<const int32_t*>(a.actions)[(uint64_t)k * a.action_stride + i];
-      pong_step(p, act, key, env, reward, done);
-      trunc = a.time_limit > 0 && p.steps >= a.time_limit;  // Wrappers.TimeLimit.cs:26-31
-      done = done || trunc;
-      if (record) {  // EnvWrapper.cs:46-55
-        ep_ret += (int32_t)reward;
-        ep_len += 1;
-        if (done) {
-          acc.add((double)ep_ret, a.ep_length ? ep_len : p.steps);
-          ep_ret = 0;
-          ep_len = 0;
-        }
-      }
-      if (autoreset && done) pong_reset(p, key, env);
-    }
-    pong_store(a, i, p);
-    if (record) {
-      static_cast<int32_t*>(a.ep_return)[i] = ep_ret;
-      if (a.ep_length) a.ep_length[i] = ep_len;
-    }
-    static_cast<float*>(a.reward)[i] = reward;
-    a.done[i] = done;
-    if (a.truncated) a.truncated[i] = trunc;
+struct PongGame {
+  using State = PongState;
+  static constexpr int kActions = 4;  // Discrete(4), Envs.Pong.cs:36
+  static __device__ __forceinline__ void load(const StepArgs& a, uint64_t i, State& s) { pong_load(a, i, s); }
+  static __device__ __forceinline__ void store(const StepArgs& a, uint64_t i, const State& s) { pong_store(a, i, s); }
+  static __device__ __forceinline__ void reset(State& s, const RngKey& key, uint64_t env) { pong_reset(s, key, env); }
+  static __device__ __forceinline__ void step(State& s, int action, const RngKey& key, uint64_t env, float& reward, bool& done) {
+    pong_step(s, action, key, env, reward, done);
   }
-  if (record) block_commit_stats(acc, a.stat_slots);
-}
-
-__global__ void __launch_bounds__(kBlock) pong_reset_kernel(StepArgs a) {
-  const RngKey key = make_key(a.seed_lo, a.seed_hi, a.tick);
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < a.num_envs; i += (uint64_t)gridDim.x * kBlock) {
-    PongState p;
-    pong_reset(p, key, a.env_index_base + i);
-    pong_store(a, i, p);
-  }
-}
-
-__global__ void __launch_bounds__(kBlock) pong_sample_kernel(StepArgs a, int32_t* out) {
-  const RngKey key = make_key(a.seed_lo, a.seed_hi, a.tick);
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < a.num_envs; i += (uint64_t)gridDim.x * kBlock)
-    out[i] = philox_block(key, a.env_index_base + i, 2, 0).below(0, 4);
-}
+  static __device__ __forceinline__ int32_t steps(const State& s) { return s.steps; }
+};
 
 // One workgroup per env.  A frame row is 160 pixels = 40 groups of four
 // pixels = 40 lanes x 12 bytes; the frame is 8400 such groups.
@@ -203,23 +154,13 @@ __global__ void __launch_bounds__(kBlock) pong_raster_kernel(StepArgs a, uint8_t
   }
 }
 
-hipError_t launch_pong_step(const StepArgs& a, int policy, dim3 grid, hipStream_t stream) {
-  if (policy == GX_POLICY_RANDOM) hipLaunchKernelGGL(pong_step_kernel<GX_POLICY_RANDOM>, grid, dim3(kBlock), 0, stream, a);
-  else hipLaunchKernelGGL(pong_step_kernel<GX_POLICY_DEVICE_ACTIONS>, grid, dim3(kBlock), 0, stream, a);
-  return hipGetLastError();
-}
-hipError_t launch_pong_reset(const StepArgs& a, dim3 grid, hipStream_t stream) {
-  hipLaunchKernelGGL(pong_reset_kernel, grid, dim3(kBlock), 0, stream, a);
-  return hipGetLastError();
-}
+hipError_t launch_pong_step(const StepArgs& a, int policy, dim3 grid, hipStream_t stream) { return launch_frame_step<PongGame>(a, policy, grid, stream); }
+hipError_t launch_pong_reset(const StepArgs& a, dim3 grid, hipStream_t stream) { return launch_frame_reset<PongGame>(a, grid, stream); }
 hipError_t launch_pong_raster(const StepArgs& a, uint8_t* frames, hipStream_t stream) {
   if (a.num_envs == 0) return hipSuccess;
   hipLaunchKernelGGL(pong_raster_kernel, dim3((unsigned)a.num_envs), dim3(kBlock), 0, stream, a, frames);
   return hipGetLastError();
 }
-hipError_t launch_pong_sample(const StepArgs& a, void* out, dim3 grid, hipStream_t stream) {
-  hipLaunchKernelGGL(pong_sample_kernel, grid, dim3(kBlock), 0, stream, a, static_cast<int32_t*>(out));
-  return hipGetLastError();
-}
+hipError_t launch_pong_sample(const StepArgs& a, void* out, dim3 grid, hipStream_t stream) { return launch_frame_sample<PongGame>(a, out, grid, stream); }
 
 }  // namespace gx
