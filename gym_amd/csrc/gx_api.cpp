@@ -69,7 +69,7 @@ struct gx_vec {
   uint8_t* d_trunc = nullptr;
   void* d_ep_return = nullptr;
   int32_t* d_ep_length = nullptr;
-  StatSlot* d_slots = nullptr;  // [num_slots] + 1 result slot
+  StatSlot* d_slots = nullptr;  // [num_slots] (one per wave of the step grid) + 1 result slot
   int num_slots = 0;
   float* d_obs = nullptr;
   uint8_t* d_frames = nullptr;
@@ -600,7 +600,7 @@ extern "C" int gx_vec_create(gx_ctx* ctx, const gx_desc* desc, gx_vec** out) {
     v->ret_per_step = env == GX_ENV_CARTPOLE ? 1 : -1;  // Envs.CartPole.cs:72, Envs.MountainCar.cs:45, Envs.Acrobot.cs:88
   }
   if (desc->flags & GX_RECORD_STATS) {
-    v->num_slots = (int)v->grid.x;
+    v->num_slots = (int)v->grid.x * (kBlock / 64);
     VEC_TRY(hipMalloc((void**)&v->d_slots, ((size_t)v->num_slots + 1) * sizeof(StatSlot)));
     VEC_TRY(launch_stats_init(v->d_slots, v->num_slots + 1, ctx->compute));
     const size_t esz = v->ep_return_f64 ? 8 : 4;
@@ -654,7 +654,7 @@ extern "C" int gx_vec_reset(gx_vec* v) {
     // EnvWrapper.cs:34-38; with auto-reset the episode length is the step counter
     const int32_t* len_row = v->d_ep_length ? v->d_ep_length : v->d_int + (size_t)(v->info.n_int - 1) * v->stride;
     uint64_t blocks = (v->n + kBlock - 1) / kBlock;
-    dim3 grid((unsigned)std::min<uint64_t>(blocks, (uint64_t)v->num_slots));
+    dim3 grid((unsigned)std::min<uint64_t>(blocks, (uint64_t)v->grid.x));
     HIP_TRY(launch_stats_flush_open(a, v->ep_return_f64, len_row, grid, c->compute));
   }
   hipError_t e;

@@ -79,9 +79,10 @@ __device__ __forceinline__ float box_sample(double u, float low, float high) {
 
 // ---------------------------------------------------------------------------
 // Episode statistics (RecordEpisodeStatistics, EnvWrapper.cs:23-58): every
-// thread accumulates the episodes its envs finished, a workgroup reduces them
-// and read-modify-writes its own slot, so the step needs no atomics.  Integer
-// valued returns stay exact in double, so those sums do not depend on order.
+// thread accumulates the episodes its envs finished, a wave reduces them and
+// adds the result to a slot only it writes, so no two waves ever meet on an
+// address.  Integer valued returns stay exact in double, so those sums do not
+// depend on order; the others are added in a fixed order (see below).
 // ---------------------------------------------------------------------------
 struct StatSlot {
   long long episodes;
@@ -125,52 +126,34 @@ __device__ __forceinline__ long long shfl_down_i64(long long v, int delta) {
 }
 
 // Called by every thread of the workgroup exactly once, at the end of the
-// kernel.  `slots` has one entry per workgroup of the largest grid the batch
-// ever launches.
+// kernel.  `slots` has one entry per wave of the largest grid the batch ever
+// launches: a wave folds its lanes with shuffles and adds the result to its own
+// slot with return-less atomics, so it neither waits for the slot to be read
+// nor meets its workgroup at a barrier before it retires.  Nobody else touches
+// that slot during the launch and launches are stream-ordered, so the order of
+// the floating-point additions into a slot is fixed.
 __device__ __forceinline__ void block_commit_stats(const StatAcc& mine, StatSlot* slots) {
-  __shared__ StatSlot wave_part[kBlock / 64];
   StatAcc a = mine;
-  // a wave that finished no episode skips the shuffles
-  bool any = __any(a.episodes != 0);
-  if (any) {
+  // a wave that finished no episode has nothing to add
+  if (!__any(a.episodes != 0)) return;
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-      a.episodes += shfl_down_i64(a.episodes, d);
-      a.sum_return += shfl_down_f64(a.sum_return, d);
-      a.sum_length += shfl_down_i64(a.sum_length, d);
-      a.sum_return_sq += shfl_down_f64(a.sum_return_sq, d);
-      double mn = shfl_down_f64(a.min_return, d), mx = shfl_down_f64(a.max_return, d);
-      a.min_return = mn < a.min_return ? mn : a.min_return;
-      a.max_return = mx > a.max_return ? mx : a.max_return;
-    }
+  for (int d = 32; d >= 1; d >>= 1) {
+    a.episodes += shfl_down_i64(a.episodes, d);
+    a.sum_return += shfl_down_f64(a.sum_return, d);
+    a.sum_length += shfl_down_i64(a.sum_length, d);
+    a.sum_return_sq += shfl_down_f64(a.sum_return_sq, d);
+    double mn = shfl_down_f64(a.min_return, d), mx = shfl_down_f64(a.max_return, d);
+    a.min_return = mn < a.min_return ? mn : a.min_return;
+    a.max_return = mx > a.max_return ? mx : a.max_return;
   }
-  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) {
-    StatSlot s;
-    s.episodes = a.episodes; s.sum_return = a.sum_return; s.sum_length = a.sum_length;
-    s.sum_return_sq = a.sum_return_sq; s.min_return = a.min_return; s.max_return = a.max_return;
-    s.pad[0] = s.pad[1] = 0;
-    wave_part[wave] = s;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    StatSlot t = wave_part[0];
-#pragma unroll
-    for (int w = 1; w < kBlock / 64; w++) {
-      const StatSlot& o = wave_part[w];
-      t.episodes += o.episodes; t.sum_return += o.sum_return; t.sum_length += o.sum_length;
-      t.sum_return_sq += o.sum_return_sq;
-      t.min_return = o.min_return < t.min_return ? o.min_return : t.min_return;
-      t.max_return = o.max_return > t.max_return ? o.max_return : t.max_return;
-    }
-    if (t.episodes != 0) {
-      StatSlot g = slots[blockIdx.x];
-      g.episodes += t.episodes; g.sum_return += t.sum_return; g.sum_length += t.sum_length;
-      g.sum_return_sq += t.sum_return_sq;
-      g.min_return = t.min_return < g.min_return ? t.min_return : g.min_return;
-      g.max_return = t.max_return > g.max_return ? t.max_return : g.max_return;
-      slots[blockIdx.x] = g;
-    }
+  if ((threadIdx.x & 63) == 0) {
+    StatSlot* g = slots + (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    atomicAdd(reinterpret_cast<unsigned long long*>(&g->episodes), (unsigned long long)a.episodes);
+    atomicAdd(reinterpret_cast<unsigned long long*>(&g->sum_length), (unsigned long long)a.sum_length);
+    unsafeAtomicAdd(&g->sum_return, a.sum_return);
+    unsafeAtomicAdd(&g->sum_return_sq, a.sum_return_sq);
+    unsafeAtomicMin(&g->min_return, a.min_return);
+    unsafeAtomicMax(&g->max_return, a.max_return);
   }
 }
 
@@ -187,7 +170,7 @@ struct StepArgs {
   uint8_t* truncated;      // [stride] or nullptr
   void* ep_return;         // [stride] int32 or double; nullptr unless RECORD_STATS
   int32_t* ep_length;      // [stride]; nullptr when the step counter serves (AUTORESET)
-  StatSlot* stat_slots;    // one per workgroup
+  StatSlot* stat_slots;    // one per wave of the grid
   float* obs;              // derived observation rows, or nullptr
   const uint32_t* table;   // tabular envs: packed transition table
   uint32_t* error_flag;    // set non-zero by a kernel that meets an action the reference throws on

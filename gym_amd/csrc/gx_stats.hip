@@ -1,5 +1,5 @@
 // Episode-statistics kernels: slot initialisation, the final reduction over
-// the per-workgroup slots, and the Reset()-time flush of open episodes.
+// the per-wave slots, and the Reset()-time flush of open episodes.
 #include "gx_device.h"
 #include "gx_launch.h"
 
