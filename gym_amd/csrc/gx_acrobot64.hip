@@ -142,7 +142,7 @@ struct Acrobot64 {
     o[5] = (float)s[3];
   }
 
-  static __device__ __forceinline__ Act sample(const Draws& d) { return d.below(0, NACT); }
+  static __device__ __forceinline__ Act sample(uint32_t w) { return word_below(w, NACT); }
 };
 
 hipError_t launch_acrobot64_step(const StepArgs& a, int policy, bool fused, dim3 grid, hipStream_t stream) {

@@ -83,7 +83,7 @@ struct CartPole {
            theta > theta_threshold_radians || steps >= 500;
     reward = !done ? 1.0f : 0.0f;
   }
-  static __device__ __forceinline__ Act sample(const Draws& d) { return d.below(0, NACT); }
+  static __device__ __forceinline__ Act sample(uint32_t w) { return word_below(w, NACT); }
 };
 
 struct MountainCar {
@@ -128,7 +128,7 @@ struct MountainCar {
     s[0] = position; s[1] = velocity;
     steps++;
   }
-  static __device__ __forceinline__ Act sample(const Draws& d) { return d.below(0, NACT); }
+  static __device__ __forceinline__ Act sample(uint32_t w) { return word_below(w, NACT); }
 };
 
 struct MountainCarContinuous {
@@ -171,7 +171,7 @@ struct MountainCarContinuous {
     steps++;
   }
   // Box([-1],[1]), Envs.MountainCarContinuous.cs:12
-  static __device__ __forceinline__ Act sample(const Draws& d) { return box_sample(d.uniform(0), -1.0f, 1.0f); }
+  static __device__ __forceinline__ Act sample(uint32_t w) { return box_sample(word_uniform(w), -1.0f, 1.0f); }
 };
 
 struct Pendulum {
@@ -228,7 +228,7 @@ struct Pendulum {
     done = false;
   }
   // Box([-2],[2]), Envs.Pendulum.cs:12
-  static __device__ __forceinline__ Act sample(const Draws& d) { return box_sample(d.uniform(0), -2.0f, 2.0f); }
+  static __device__ __forceinline__ Act sample(uint32_t w) { return box_sample(word_uniform(w), -2.0f, 2.0f); }
 };
 
 struct Acrobot {
@@ -328,7 +328,7 @@ struct Acrobot {
     done = above || steps >= 500;
     reward = done ? 0.0f : -1.0f;
   }
-  static __device__ __forceinline__ Act sample(const Draws& d) { return d.below(0, NACT); }
+  static __device__ __forceinline__ Act sample(uint32_t w) { return word_below(w, NACT); }
 };
 
 hipError_t launch_classic_step(int env_id, const StepArgs& a, int mode, int policy, bool fused, bool bounded, dim3 grid,

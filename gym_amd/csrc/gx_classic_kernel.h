@@ -151,7 +151,10 @@ struct RegState<E, std::void_t<decltype(E::NR)>> {
 #define GX_FUSED_MIN_WAVES 1
 #endif
 
-template <class E, int MODE, int POLICY, bool FUSED, bool BOUNDED>
+// CACHED (fused K-step rollouts with the random policy): the policy block of four ticks is kept
+// in registers, so the generator runs once every four steps; the single-step kernels draw
+// the block and use one word of it (16 registers per lane fewer, one more resident wave).
+template <class E, int MODE, int POLICY, bool FUSED, bool BOUNDED, bool CACHED = false>
 __global__ void __launch_bounds__(kBlock, (FUSED && BOUNDED) ? GX_FUSED_MIN_WAVES : 1) classic_step_kernel(StepArgs a) {
   using Real = typename E::Real;
   using Act = typename E::Act;
@@ -207,16 +210,25 @@ __global__ void __launch_bounds__(kBlock, (FUSED && BOUNDED) ? GX_FUSED_MIN_WAVE
 
     Rew reward[W];
     bool done[W], trunc[W];
+    Draws policy[CACHED ? W : 1];
+    const uint64_t env0 = a.env_index_base + q * W;
     for (int k = 0; k < a.k_steps; k++) {
-      const RngKey key = make_key(a.seed_lo, a.seed_hi, a.tick + (uint64_t)k);
+      const uint64_t tick = a.tick + (uint64_t)k;
+      const RngKey key = make_key(a.seed_lo, a.seed_hi, tick);
       Act act[W];
       if (POLICY == GX_POLICY_DEVICE_ACTIONS)
         load_row<Act, W>(static_cast<const Act*>(a.actions) + (uint64_t)k * a.action_stride, q, act);
-      const uint64_t env0 = a.env_index_base + q * W;
+      if (CACHED && POLICY == GX_POLICY_RANDOM && (k == 0 || (tick & 3) == 0)) {
+#pragma unroll
+        for (int j = 0; j < W; j++) policy[CACHED ? j : 0] = policy_block(a.seed_lo, a.seed_hi, tick, env0 + j);
+      }
       uint32_t pending = 0;  // envs of this lane that finished in this step
 #pragma unroll
       for (int j = 0; j < W; j++) {
-        if (POLICY == GX_POLICY_RANDOM) act[j] = E::sample(philox_block(key, env0 + j, 2, 0));
+        if (POLICY == GX_POLICY_RANDOM) {
+          if (!CACHED) policy[0] = policy_block(a.seed_lo, a.seed_hi, tick, env0 + j);
+          act[j] = E::sample(policy_word(policy[CACHED ? j : 0], tick));
+        }
         if (E::kCheckAction && POLICY == GX_POLICY_DEVICE_ACTIONS) {
           if (!E::action_valid(act[j]) && q * W + j < a.num_envs) atomicOr(a.error_flag, 1u);
         }
@@ -348,9 +360,8 @@ __global__ void __launch_bounds__(kBlock) classic_reset_kernel(StepArgs a, int o
 template <class E>
 __global__ void __launch_bounds__(kBlock) classic_sample_kernel(StepArgs a, void* out) {
   using Act = typename E::Act;
-  const RngKey key = make_key(a.seed_lo, a.seed_hi, a.tick);
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < a.num_envs; i += (uint64_t)gridDim.x * kBlock)
-    static_cast<Act*>(out)[i] = E::sample(philox_block(key, a.env_index_base + i, 2, 0));
+    static_cast<Act*>(out)[i] = E::sample(policy_word(policy_block(a.seed_lo, a.seed_hi, a.tick, a.env_index_base + i), a.tick));
 }
 
 // -------------------------------------------------------------- dispatch ---
@@ -359,7 +370,9 @@ __global__ void __launch_bounds__(kBlock) classic_sample_kernel(StepArgs a, void
 template <class E, int MODE, int POLICY>
 static void launch_step_variant(const StepArgs& a, bool fused, bool bounded, dim3 grid, hipStream_t stream) {
   if (E::kAlwaysBounded) bounded = true;
-  if (fused && bounded) {
+  if (fused && bounded && POLICY == GX_POLICY_RANDOM && a.k_steps > 1) {
+    hipLaunchKernelGGL((classic_step_kernel<E, MODE, POLICY, true, true, POLICY == GX_POLICY_RANDOM>), grid, dim3(kBlock), 0, stream, a);
+  } else if (fused && bounded) {
     hipLaunchKernelGGL((classic_step_kernel<E, MODE, POLICY, true, true>), grid, dim3(kBlock), 0, stream, a);
   } else if constexpr (E::kAlwaysBounded) {
     hipLaunchKernelGGL((classic_step_kernel<E, MODE, POLICY, false, true>), grid, dim3(kBlock), 0, stream, a);

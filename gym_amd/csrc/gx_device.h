@@ -24,6 +24,9 @@ constexpr int kStatFields = 6;
 // `tick` counts the Reset()/Step() calls made on the batch before the one that
 // consumes the draw, so no per-env RNG state is stored or moved.
 // Streams: 0 = Reset draws, 1 = draws made inside Step, 2 = random policy.
+// The policy stream takes one draw per env per tick, so four consecutive ticks
+// share a block: tick t reads word t % 4 of the block whose counter holds
+// t / 4, and a fused K-step rollout runs the generator once every four steps.
 // ---------------------------------------------------------------------------
 struct RngKey {
   uint32_t k0, k1;     // seed
@@ -69,6 +72,18 @@ __device__ __forceinline__ Draws philox_block(const RngKey& key, uint64_t env, u
   d.w[0] = c0; d.w[1] = c1; d.w[2] = c2; d.w[3] = c3;
   return d;
 }
+
+// Policy stream: the block shared by ticks 4m .. 4m+3, and tick t's word of it.
+__device__ __forceinline__ Draws policy_block(uint32_t seed_lo, uint32_t seed_hi, uint64_t tick, uint64_t env) {
+  return philox_block(make_key(seed_lo, seed_hi, tick >> 2), env, 2, 0);
+}
+__device__ __forceinline__ uint32_t policy_word(const Draws& d, uint64_t tick) {
+  const uint32_t i = (uint32_t)tick & 3u;
+  return i == 0 ? d.w[0] : (i == 1 ? d.w[1] : (i == 2 ? d.w[2] : d.w[3]));
+}
+// the two ways a draw is consumed: NextDouble() and Next(n)
+__device__ __forceinline__ double word_uniform(uint32_t w) { return (double)w * 0x1.0p-32; }
+__device__ __forceinline__ int32_t word_below(uint32_t w, uint32_t n) { return (int32_t)__umulhi(w, n); }
 
 // Spaces.Box.cs:30 -- (float)(NextDouble() * (High - Low) + Low), the range
 // being a binary32 subtraction promoted to double.

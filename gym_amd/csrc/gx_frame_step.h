@@ -28,11 +28,15 @@ __global__ void __launch_bounds__(kBlock) frame_step_kernel(StepArgs a) {
     const uint64_t env = a.env_index_base + i;
     float reward = 0.0f;
     bool done = false, trunc = false;
+    Draws policy;
     for (int k = 0; k < a.k_steps; k++) {
-      const RngKey key = make_key(a.seed_lo, a.seed_hi, a.tick + (uint64_t)k);
+      const uint64_t tick = a.tick + (uint64_t)k;
+      const RngKey key = make_key(a.seed_lo, a.seed_hi, tick);
       int act;
-      if (POLICY == GX_POLICY_RANDOM) act = philox_block(key, env, 2, 0).below(0, G::kActions);  // Discrete.Sample, Spaces.Discrete.cs:18
-      else act = static_cast<const int32_t*>(a.actions)[(uint64_t)k * a.action_stride + i];
+      if (POLICY == GX_POLICY_RANDOM) {  // Discrete.Sample, Spaces.Discrete.cs:18
+        if (k == 0 || (tick & 3) == 0) policy = policy_block(a.seed_lo, a.seed_hi, tick, env);
+        act = word_below(policy_word(policy, tick), G::kActions);
+      } else act = static_cast<const int32_t*>(a.actions)[(uint64_t)k * a.action_stride + i];
       G::step(s, act, key, env, reward, done);
       trunc = a.time_limit > 0 && G::steps(s) >= a.time_limit;  // Wrappers.TimeLimit.cs:26-31
       done = done || trunc;
@@ -71,9 +75,8 @@ __global__ void __launch_bounds__(kBlock) frame_reset_kernel(StepArgs a) {
 
 template <class G>
 __global__ void __launch_bounds__(kBlock) frame_sample_kernel(StepArgs a, int32_t* out) {
-  const RngKey key = make_key(a.seed_lo, a.seed_hi, a.tick);
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < a.num_envs; i += (uint64_t)gridDim.x * kBlock)
-    out[i] = philox_block(key, a.env_index_base + i, 2, 0).below(0, G::kActions);
+    out[i] = word_below(policy_word(policy_block(a.seed_lo, a.seed_hi, a.tick, a.env_index_base + i), a.tick), G::kActions);
 }
 
 template <class G>

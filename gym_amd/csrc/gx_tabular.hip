@@ -88,14 +88,15 @@ __global__ void __launch_bounds__(kBlock) tabular_step_kernel(StepArgs a) {
     float reward[4];
     bool done[4], trunc[4];
     for (int k = 0; k < a.k_steps; k++) {
-      const RngKey key = make_key(a.seed_lo, a.seed_hi, a.tick + (uint64_t)k);
+      const uint64_t tick = a.tick + (uint64_t)k;
+      const RngKey key = make_key(a.seed_lo, a.seed_hi, tick);
       int32_t act[4];
       if (POLICY == GX_POLICY_DEVICE_ACTIONS)
         load4i(static_cast<const int32_t*>(a.actions) + (uint64_t)k * a.action_stride, q, act);
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const uint64_t env = a.env_index_base + q * 4 + j;
-        if (POLICY == GX_POLICY_RANDOM) act[j] = philox_block(key, env, 2, 0).below(0, A);
+        if (POLICY == GX_POLICY_RANDOM) act[j] = word_below(policy_word(policy_block(a.seed_lo, a.seed_hi, tick, env), tick), A);
         const int col = (uint32_t)act[j] < (uint32_t)A ? act[j] : A;
         int o = 0;
         if (O > 1 && col < A) o = philox_block(key, env, 1, 0).below(0, O);
@@ -161,14 +162,14 @@ __global__ void __launch_bounds__(kBlock) dummy_step_kernel(StepArgs a) {
     float reward[4];
     bool done[4], trunc[4];
     for (int k = 0; k < a.k_steps; k++) {
-      const RngKey key = make_key(a.seed_lo, a.seed_hi, a.tick + (uint64_t)k);
+      const uint64_t tick = a.tick + (uint64_t)k;
       int32_t act[4];
       if (POLICY == GX_POLICY_DEVICE_ACTIONS)
         load4i(static_cast<const int32_t*>(a.actions) + (uint64_t)k * a.action_stride, q, act);
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        const uint64_t env = a.env_index_base + q * 4 + j;
-        if (POLICY == GX_POLICY_RANDOM) act[j] = philox_block(key, env, 2, 0).below(0, 3);  // Discrete(3), DummyEnv.cs:14
+        if (POLICY == GX_POLICY_RANDOM)  // Discrete(3), DummyEnv.cs:14
+          act[j] = word_below(policy_word(policy_block(a.seed_lo, a.seed_hi, tick, a.env_index_base + q * 4 + j), tick), 3);
         st[j] += act[j];
         steps[j] += 1;
         reward[j] = (float)st[j];
@@ -219,9 +220,8 @@ __global__ void __launch_bounds__(kBlock) tabular_reset_kernel(StepArgs a) {
 }
 
 __global__ void __launch_bounds__(kBlock) tabular_sample_kernel(StepArgs a, int32_t nact, int32_t* out) {
-  const RngKey key = make_key(a.seed_lo, a.seed_hi, a.tick);
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < a.num_envs; i += (uint64_t)gridDim.x * kBlock)
-    out[i] = philox_block(key, a.env_index_base + i, 2, 0).below(0, nact);
+    out[i] = word_below(policy_word(policy_block(a.seed_lo, a.seed_hi, a.tick, a.env_index_base + i), a.tick), nact);
 }
 
 hipError_t launch_tabular_step(int env_id, const StepArgs& a, int policy, dim3 grid, size_t lds_bytes, hipStream_t stream) {

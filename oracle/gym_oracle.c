@@ -67,6 +67,13 @@ void gxo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 
 uint32_t gxo_rng_u32(uint64_t seed, uint64_t env_index, uint64_t tick, uint32_t stream, uint32_t draw) {
   uint32_t ctr[4], key[2], out[4];
+  if (stream == 2) {
+    /* the policy stream takes one draw per env per tick: four consecutive ticks share a
+     * block (counter tick / 4), tick t reading word t % 4, so that a fused K-step rollout
+     * runs the generator once every four steps */
+    draw = (uint32_t)(tick & 3u);
+    tick >>= 2;
+  }
   ctr[0] = (uint32_t)env_index;
   ctr[1] = (uint32_t)(env_index >> 32);
   ctr[2] = (uint32_t)tick;

@@ -43,7 +43,10 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 
 
 def rng_u32(seed, env, tick, stream, draw):
-    """word (draw & 3) of the Philox block (draw >> 2) of this (env, tick, stream)"""
+    """word (draw & 3) of the Philox block (draw >> 2) of this (env, tick, stream); the policy
+    stream (2) has one draw per tick, word tick % 4 of the block of tick // 4"""
+    if stream == 2:
+        draw, tick = tick & 3, tick >> 2
     env = np.asarray(env, np.uint64)
     tick = int(tick)
     c3 = np.uint64((stream << 24) | (((tick >> 32) & 0xFF) << 16) | ((draw >> 2) & 0xFFFF))

@@ -21,9 +21,12 @@ def test_philox_random123_vectors(oracle):
 
 
 def test_uniform_range_and_keying(oracle):
-    us = [oracle.rng_uniform(7, e, t, s, d) for e in range(4) for t in range(3) for s in range(3) for d in range(4)]
+    us = [oracle.rng_uniform(7, e, t, s, d) for e in range(4) for t in range(3) for s in range(2) for d in range(4)]
+    us += [oracle.rng_uniform(7, e, t, 2, 0) for e in range(4) for t in range(12)]  # the policy stream: one draw per tick
     assert all(0.0 <= u < 1.0 for u in us)
     assert len(set(us)) == len(us)
+    # ticks 4m .. 4m+3 of the policy stream are the four words of one block: counter (env, 0, m, 2 << 24)
+    assert [oracle.rng_u32(7, 5, 8 + i, 2, 0) for i in range(4)] == oracle.philox([5, 0, 2, 2 << 24], [7, 0])
     assert all(0 <= oracle.rng_below(7, e, 0, 2, 0, 3) < 3 for e in range(100))
 
 
