@@ -755,8 +755,11 @@ extern "C" int gx_vec_step_async(gx_vec* v, const void* h_actions, void* h_obs, 
     // torque[action] throws IndexOutOfRangeException (Envs.Acrobot.cs:45,51);
     // the whole call is rejected before any env is stepped
     const int32_t* act = static_cast<const int32_t*>(h_actions);
-    for (uint64_t i = 0; i < v->n; i++)
-      if ((uint32_t)act[i] > 2u) return fail(GX_ERR_INVALID, "Acrobot: action %d of env %llu is outside {0,1,2}", act[i], (unsigned long long)i);
+    uint32_t bad = 0;  // branch-free scan (vectorises); the offender is looked up only if there is one
+    for (uint64_t i = 0; i < v->n; i++) bad |= (uint32_t)((uint32_t)act[i] > 2u);
+    if (bad)
+      for (uint64_t i = 0; i < v->n; i++)
+        if ((uint32_t)act[i] > 2u) return fail(GX_ERR_INVALID, "Acrobot: action %d of env %llu is outside {0,1,2}", act[i], (unsigned long long)i);
   }
   HIP_TRY(hipMemcpyAsync(v->d_actions, h_actions, v->n * 4, hipMemcpyHostToDevice, c->copy));
   HIP_TRY(hipEventRecord(c->ev_in, c->copy));
