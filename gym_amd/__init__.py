@@ -6,10 +6,10 @@ from .env import (ActionWrapper, Env, EnvWrapper, ObservationWrapper, RecordEpis
 from .envs import (Acrobot, Breakout, CartPole, CliffWalking, DummyEnv, FrozenLake, MountainCar,
                    MountainCarContinuous, Pendulum, Pong, SpaceInvaders, Taxi)
 from .registry import EnvRegistry, RegisterAll
-from .spaces import Box, Discrete
+from .spaces import Box, Dict, Discrete, MultiBinary, MultiDiscrete, Tuple
 from .vector_env import VectorEnv
 
 __all__ = ["spaces", "Env", "EnvWrapper", "ObservationWrapper", "ActionWrapper", "RewardWrapper",
            "RecordEpisodeStatistics", "TimeLimit", "CartPole", "MountainCar", "MountainCarContinuous", "Pendulum",
            "Acrobot", "FrozenLake", "Taxi", "CliffWalking", "Pong", "Breakout", "SpaceInvaders", "DummyEnv", "EnvRegistry", "RegisterAll",
-           "Box", "Discrete", "VectorEnv"]
+           "Box", "Discrete", "MultiBinary", "MultiDiscrete", "Tuple", "Dict", "VectorEnv"]

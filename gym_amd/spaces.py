@@ -1,5 +1,5 @@
-"""Box and Discrete, with the members agents read through duck typing
-(Gymnasium/Spaces.Box.cs, Spaces.Discrete.cs, Spaces.Space.cs).
+"""Box, Discrete and the composite spaces, with the members agents read through duck typing
+(Gymnasium/Spaces.*.cs).
 
 Host-side metadata only.  Sample() uses a numpy generator per space (the
 reference owns an unseeded System.Random per space, Spaces.Box.cs:14); batched
@@ -68,3 +68,73 @@ class Discrete(Space):
 
     def Contains(self, x):
         return 0 <= int(x) < self.N
+
+
+class MultiBinary(Space):
+    """Spaces.MultiBinary.cs:8-34"""
+
+    def __init__(self, n, seed=None):
+        self.N = int(n)
+        self._rng = np.random.default_rng(seed)
+
+    @property
+    def Shape(self):
+        return [self.N]
+
+    def Sample(self):
+        return [bool(b) for b in self._rng.integers(0, 2, self.N)]
+
+    def Contains(self, x):
+        return len(x) == self.N  # the reference checks the length only (Spaces.MultiBinary.cs:30-33)
+
+
+class MultiDiscrete(Space):
+    """Spaces.MultiDiscrete.cs:8-39"""
+
+    def __init__(self, nvec, seed=None):
+        self.Nvec = [int(n) for n in nvec]
+        self._rng = np.random.default_rng(seed)
+
+    @property
+    def Shape(self):
+        return [len(self.Nvec)]
+
+    def Sample(self):
+        return [int(self._rng.integers(0, n)) for n in self.Nvec]
+
+    def Contains(self, x):
+        return len(x) == len(self.Nvec) and all(0 <= int(v) < n for v, n in zip(x, self.Nvec))
+
+
+class Tuple(Space):
+    """Spaces.Tuple.cs:8-39"""
+
+    def __init__(self, spaces):
+        self.Spaces = list(spaces)
+
+    @property
+    def Shape(self):
+        return [len(self.Spaces)]  # the number of elements (Spaces.Tuple.cs:11)
+
+    def Sample(self):
+        return [s.Sample() for s in self.Spaces]
+
+    def Contains(self, x):
+        return len(x) == len(self.Spaces) and all(s.Contains(v) for s, v in zip(self.Spaces, x))
+
+
+class Dict(Space):
+    """Spaces.Dict.cs:8-39"""
+
+    def __init__(self, spaces):
+        self.Spaces = dict(spaces)
+
+    @property
+    def Shape(self):
+        return [len(self.Spaces)]  # the number of keys (Spaces.Dict.cs:11)
+
+    def Sample(self):
+        return {k: s.Sample() for k, s in self.Spaces.items()}
+
+    def Contains(self, x):
+        return all(k in x and s.Contains(x[k]) for k, s in self.Spaces.items())

@@ -24,6 +24,21 @@ def test_box_and_discrete_members():
     assert not d.Contains(3) and not d.Contains(-1)
 
 
+def test_composite_spaces():
+    """Spaces.MultiBinary.cs, Spaces.MultiDiscrete.cs, Spaces.Tuple.cs, Spaces.Dict.cs"""
+    mb = G.MultiBinary(5)
+    assert mb.Shape == [5] and len(mb.Sample()) == 5 and mb.Contains([True] * 5) and not mb.Contains([True] * 4)
+    md = G.MultiDiscrete([3, 5, 2])
+    assert md.Shape == [3] and all(md.Contains(md.Sample()) for _ in range(50))
+    assert not md.Contains([3, 0, 0]) and not md.Contains([0, 0]) and not md.Contains([0, -1, 0])
+    tp = G.Tuple([G.Discrete(3), G.Box([0.0], [1.0])])
+    assert tp.Shape == [2] and all(tp.Contains(tp.Sample()) for _ in range(20))
+    assert not tp.Contains([3, [0.5]]) and not tp.Contains([1])
+    dc = G.Dict({"a": G.Discrete(2), "b": md})
+    assert dc.Shape == [2] and all(dc.Contains(dc.Sample()) for _ in range(20))
+    assert not dc.Contains({"a": 1}) and not dc.Contains({"a": 2, "b": [0, 0, 0]})
+
+
 def test_registry():
     """EnvRegistry.cs:13-34, GymnasiumRegistration.cs:10-28"""
     G.RegisterAll()
