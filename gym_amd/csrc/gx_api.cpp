@@ -585,7 +585,8 @@ extern "C" int gx_vec_create(gx_ctx* ctx, const gx_desc* desc, gx_vec** out) {
   // by 4-10 %.  Small batches keep at least four workgroups per CU.
   {
     uint64_t groups = (v->n + v->envs_per_lane - 1) / v->envs_per_lane;
-    uint64_t blocks = (groups + kBlock - 1) / kBlock;
+    const uint64_t block = v->is_classic ? kClassicBlock : kBlock;
+    uint64_t blocks = (groups + block - 1) / block;
     uint64_t cap = std::max<uint64_t>((blocks + 1) / 2, (uint64_t)ctx->num_cus * 4);
     if (const char* s = std::getenv("GYMX_GRID_BLOCKS")) {
       long long b = std::atoll(s);
@@ -600,7 +601,8 @@ extern "C" int gx_vec_create(gx_ctx* ctx, const gx_desc* desc, gx_vec** out) {
     v->ret_per_step = env == GX_ENV_CARTPOLE ? 1 : -1;  // Envs.CartPole.cs:72, Envs.MountainCar.cs:45, Envs.Acrobot.cs:88
   }
   if (desc->flags & GX_RECORD_STATS) {
-    v->num_slots = (int)v->grid.x * (kBlock / 64);
+    // one slot per wave of the step grid, and never fewer than one kBlock workgroup has waves
+    v->num_slots = std::max((int)v->grid.x * ((v->is_classic ? kClassicBlock : kBlock) / 64), kBlock / 64);
     VEC_TRY(hipMalloc((void**)&v->d_slots, ((size_t)v->num_slots + 1) * sizeof(StatSlot)));
     VEC_TRY(launch_stats_init(v->d_slots, v->num_slots + 1, ctx->compute));
     const size_t esz = v->ep_return_f64 ? 8 : 4;
@@ -654,7 +656,7 @@ extern "C" int gx_vec_reset(gx_vec* v) {
     // EnvWrapper.cs:34-38; with auto-reset the episode length is the step counter
     const int32_t* len_row = v->d_ep_length ? v->d_ep_length : v->d_int + (size_t)(v->info.n_int - 1) * v->stride;
     uint64_t blocks = (v->n + kBlock - 1) / kBlock;
-    dim3 grid((unsigned)std::min<uint64_t>(blocks, (uint64_t)v->grid.x));
+    dim3 grid((unsigned)std::min<uint64_t>(blocks, (uint64_t)v->num_slots / (kBlock / 64)));  // the flush kernel runs kBlock threads
     HIP_TRY(launch_stats_flush_open(a, v->ep_return_f64, len_row, grid, c->compute));
   }
   hipError_t e;

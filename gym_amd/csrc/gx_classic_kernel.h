@@ -155,7 +155,7 @@ struct RegState<E, std::void_t<decltype(E::NR)>> {
 // in registers, so the generator runs once every four steps; the single-step kernels draw
 // the block and use one word of it (16 registers per lane fewer, one more resident wave).
 template <class E, int MODE, int POLICY, bool FUSED, bool BOUNDED, bool CACHED = false>
-__global__ void __launch_bounds__(kBlock, (FUSED && BOUNDED) ? GX_FUSED_MIN_WAVES : 1) classic_step_kernel(StepArgs a) {
+__global__ void __launch_bounds__(kClassicBlock, (FUSED && BOUNDED) ? GX_FUSED_MIN_WAVES : 1) classic_step_kernel(StepArgs a) {
   using Real = typename E::Real;
   using Act = typename E::Act;
   using Rew = typename E::Rew;
@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(kBlock, (FUSED && BOUNDED) ? GX_FUSED_MIN_WAVE
   ThreadStats<EpRet> acc;
 
   const uint64_t ngroups = (a.num_envs + (W - 1)) / W;
-  for (uint64_t it = (uint64_t)blockIdx.x * kBlock + threadIdx.x; it < ngroups; it += (uint64_t)gridDim.x * kBlock) {
+  for (uint64_t it = (uint64_t)blockIdx.x * kClassicBlock + threadIdx.x; it < ngroups; it += (uint64_t)gridDim.x * kClassicBlock) {
     // consecutive launches sweep the batch in opposite directions: the rows a sweep touched
     // last are still in the 256 MiB memory-side cache when the next sweep starts there
     const uint64_t q = a.reverse ? ngroups - 1 - it : it;
@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(kBlock, (FUSED && BOUNDED) ? GX_FUSED_MIN_WAVE
 // Reset() of every env, or (when only_observe) just the derived observation
 // rows of the current state.
 template <class E>
-__global__ void __launch_bounds__(kBlock) classic_reset_kernel(StepArgs a, int only_observe) {
+__global__ void __launch_bounds__(kClassicBlock) classic_reset_kernel(StepArgs a, int only_observe) {
   using Real = typename E::Real;
   constexpr int NS = E::NS;
   constexpr int NR = RegState<E>::value;
@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(kBlock) classic_reset_kernel(StepArgs a, int o
   Real* const sreal = static_cast<Real*>(a.state_real);
   const RngKey key = make_key(a.seed_lo, a.seed_hi, a.tick);
   const uint64_t ngroups = (a.num_envs + (W - 1)) / W;
-  for (uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q < ngroups; q += (uint64_t)gridDim.x * kBlock) {
+  for (uint64_t q = (uint64_t)blockIdx.x * kClassicBlock + threadIdx.x; q < ngroups; q += (uint64_t)gridDim.x * kClassicBlock) {
     Real s[W][NR];
     if (only_observe) {
 #pragma unroll
@@ -358,9 +358,9 @@ __global__ void __launch_bounds__(kBlock) classic_reset_kernel(StepArgs a, int o
 
 // Actions of the random policy for one tick, for harnesses that replay them.
 template <class E>
-__global__ void __launch_bounds__(kBlock) classic_sample_kernel(StepArgs a, void* out) {
+__global__ void __launch_bounds__(kClassicBlock) classic_sample_kernel(StepArgs a, void* out) {
   using Act = typename E::Act;
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < a.num_envs; i += (uint64_t)gridDim.x * kBlock)
+  for (uint64_t i = (uint64_t)blockIdx.x * kClassicBlock + threadIdx.x; i < a.num_envs; i += (uint64_t)gridDim.x * kClassicBlock)
     static_cast<Act*>(out)[i] = E::sample(policy_word(policy_block(a.seed_lo, a.seed_hi, a.tick, a.env_index_base + i), a.tick));
 }
 
@@ -371,13 +371,13 @@ template <class E, int MODE, int POLICY>
 static void launch_step_variant(const StepArgs& a, bool fused, bool bounded, dim3 grid, hipStream_t stream) {
   if (E::kAlwaysBounded) bounded = true;
   if (fused && bounded && POLICY == GX_POLICY_RANDOM && a.k_steps > 1) {
-    hipLaunchKernelGGL((classic_step_kernel<E, MODE, POLICY, true, true, POLICY == GX_POLICY_RANDOM>), grid, dim3(kBlock), 0, stream, a);
+    hipLaunchKernelGGL((classic_step_kernel<E, MODE, POLICY, true, true, POLICY == GX_POLICY_RANDOM>), grid, dim3(kClassicBlock), 0, stream, a);
   } else if (fused && bounded) {
-    hipLaunchKernelGGL((classic_step_kernel<E, MODE, POLICY, true, true>), grid, dim3(kBlock), 0, stream, a);
+    hipLaunchKernelGGL((classic_step_kernel<E, MODE, POLICY, true, true>), grid, dim3(kClassicBlock), 0, stream, a);
   } else if constexpr (E::kAlwaysBounded) {
-    hipLaunchKernelGGL((classic_step_kernel<E, MODE, POLICY, false, true>), grid, dim3(kBlock), 0, stream, a);
+    hipLaunchKernelGGL((classic_step_kernel<E, MODE, POLICY, false, true>), grid, dim3(kClassicBlock), 0, stream, a);
   } else {
-    hipLaunchKernelGGL((classic_step_kernel<E, MODE, POLICY, false, false>), grid, dim3(kBlock), 0, stream, a);
+    hipLaunchKernelGGL((classic_step_kernel<E, MODE, POLICY, false, false>), grid, dim3(kClassicBlock), 0, stream, a);
   }
 }
 
@@ -396,13 +396,13 @@ static hipError_t launch_step_env(const StepArgs& a, int mode, int policy, bool 
 
 template <class E>
 static hipError_t launch_reset_env(const StepArgs& a, int only_observe, dim3 grid, hipStream_t stream) {
-  hipLaunchKernelGGL(classic_reset_kernel<E>, grid, dim3(kBlock), 0, stream, a, only_observe);
+  hipLaunchKernelGGL(classic_reset_kernel<E>, grid, dim3(kClassicBlock), 0, stream, a, only_observe);
   return hipGetLastError();
 }
 
 template <class E>
 static hipError_t launch_sample_env(const StepArgs& a, void* out, dim3 grid, hipStream_t stream) {
-  hipLaunchKernelGGL(classic_sample_kernel<E>, grid, dim3(kBlock), 0, stream, a, out);
+  hipLaunchKernelGGL(classic_sample_kernel<E>, grid, dim3(kClassicBlock), 0, stream, a, out);
   return hipGetLastError();
 }
 

@@ -11,6 +11,9 @@
 namespace gx {
 
 constexpr int kBlock = 256;          // threads per workgroup (4 waves)
+// The classic-control kernels run one wave per workgroup: measured on the CartPole step at
+// 16 Mi envs, 64 / 128 / 256 / 512 threads take 0.142 / 0.146 / 0.1465 / 0.150 ms.
+constexpr int kClassicBlock = 64;
 constexpr int kEnvsPerThread = 4;    // one 16-byte vector per component per lane
 constexpr int kStatFields = 6;
 
@@ -162,7 +165,7 @@ __device__ __forceinline__ void block_commit_stats(const StatAcc& mine, StatSlot
     a.max_return = mx > a.max_return ? mx : a.max_return;
   }
   if ((threadIdx.x & 63) == 0) {
-    StatSlot* g = slots + (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    StatSlot* g = slots + (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     atomicAdd(reinterpret_cast<unsigned long long*>(&g->episodes), (unsigned long long)a.episodes);
     atomicAdd(reinterpret_cast<unsigned long long*>(&g->sum_length), (unsigned long long)a.sum_length);
     unsafeAtomicAdd(&g->sum_return, a.sum_return);
