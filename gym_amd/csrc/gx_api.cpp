@@ -59,6 +59,7 @@ struct gx_vec {
   std::string map;
   uint64_t n = 0, stride = 0, tick = 0;
   int envs_per_lane = 4;
+  int block = 256;  // threads per workgroup of this batch's step kernels
   bool is_classic = false, is_tabular = false, is_frame = false, is_acrobot64 = false;  // is_frame: Pong, Breakout, SpaceInvaders
   bool ep_return_f64 = false;
   // device memory
@@ -448,7 +449,7 @@ int launch_step(gx_vec* v, const void* d_actions, int k_steps, uint64_t action_s
   const bool bounded = (v->desc.flags & GX_AUTORESET) && !v->state_dirty;
   if (v->is_acrobot64) e = launch_acrobot64_step(a, policy, fused, v->grid, stream);
   else if (v->is_classic) e = launch_classic_step(v->desc.env_id, a, v->desc.mode, policy, fused, bounded, v->grid, stream);
-  else if (v->is_tabular) e = launch_tabular_step(v->desc.env_id, a, policy, v->grid, v->table_lds_bytes, stream);
+  else if (v->is_tabular) e = launch_tabular_step(v->desc.env_id, a, policy, v->grid, v->block, v->table_lds_bytes, stream);
   else {
     e = frame_step(v, a, policy, stream);
     if (e == hipSuccess) e = frame_raster(v, a, stream);
@@ -585,8 +586,16 @@ extern "C" int gx_vec_create(gx_ctx* ctx, const gx_desc* desc, gx_vec** out) {
   // by 4-10 %.  Small batches keep at least four workgroups per CU.
   {
     uint64_t groups = (v->n + v->envs_per_lane - 1) / v->envs_per_lane;
-    const uint64_t block = v->is_classic ? kClassicBlock : kBlock;
-    uint64_t blocks = (groups + block - 1) / block;
+    v->block = kBlock;
+    if (v->is_classic) v->block = kClassicBlock;
+    if (v->is_tabular) {
+      v->block = table.size() * 4 <= kSmallTableBytes ? kTabularBlockSmallTable : kTabularBlock;
+      if (const char* s = std::getenv("GYMX_TABULAR_BLOCK")) {  // tuning aid: 64, 128 or 256
+        const int b = std::atoi(s);
+        if (b == 64 || b == 128 || b == 256) v->block = b;
+      }
+    }
+    uint64_t blocks = (groups + v->block - 1) / v->block;
     uint64_t cap = std::max<uint64_t>((blocks + 1) / 2, (uint64_t)ctx->num_cus * 4);
     if (const char* s = std::getenv("GYMX_GRID_BLOCKS")) {
       long long b = std::atoll(s);
@@ -602,7 +611,7 @@ extern "C" int gx_vec_create(gx_ctx* ctx, const gx_desc* desc, gx_vec** out) {
   }
   if (desc->flags & GX_RECORD_STATS) {
     // one slot per wave of the step grid, and never fewer than one kBlock workgroup has waves
-    v->num_slots = std::max((int)v->grid.x * ((v->is_classic ? kClassicBlock : kBlock) / 64), kBlock / 64);
+    v->num_slots = std::max((int)v->grid.x * (v->block / 64), kBlock / 64);
     VEC_TRY(hipMalloc((void**)&v->d_slots, ((size_t)v->num_slots + 1) * sizeof(StatSlot)));
     VEC_TRY(launch_stats_init(v->d_slots, v->num_slots + 1, ctx->compute));
     const size_t esz = v->ep_return_f64 ? 8 : 4;

@@ -14,6 +14,12 @@ constexpr int kBlock = 256;          // threads per workgroup (4 waves)
 // The classic-control kernels run one wave per workgroup: measured on the CartPole step at
 // 16 Mi envs, 64 / 128 / 256 / 512 threads take 0.142 / 0.146 / 0.1465 / 0.150 ms.
 constexpr int kClassicBlock = 64;
+// The tabular step kernels stage the transition table in LDS once per workgroup, so their
+// workgroup size follows the table.  At 64 Mi envs, 256 / 128 threads: FrozenLake 4x4
+// (352 bytes) 0.283 / 0.271 ms, 8x8 (1.3 KB) 0.279 / 0.266 ms, slippery 8x8 (3.9 KB)
+// 0.343 / 0.360 ms, full Taxi-v3 (14 KB) 0.355 / 0.418 ms.
+constexpr int kTabularBlock = 256, kTabularBlockSmallTable = 128;
+constexpr size_t kSmallTableBytes = 2048;
 constexpr int kEnvsPerThread = 4;    // one 16-byte vector per component per lane
 constexpr int kStatFields = 6;
 

@@ -21,7 +21,7 @@ hipError_t launch_acrobot64_reset(const StepArgs& a, int only_observe, dim3 grid
 hipError_t launch_acrobot64_sample(const StepArgs& a, void* out, dim3 grid, hipStream_t stream);
 
 // table-driven envs and DummyEnv (gx_tabular.hip)
-hipError_t launch_tabular_step(int env_id, const StepArgs& a, int policy, dim3 grid, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_tabular_step(int env_id, const StepArgs& a, int policy, dim3 grid, int block, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_tabular_reset(int env_id, const StepArgs& a, dim3 grid, hipStream_t stream);
 hipError_t launch_tabular_sample(int env_id, const StepArgs& a, void* out, dim3 grid, hipStream_t stream);
 

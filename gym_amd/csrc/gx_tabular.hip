@@ -48,13 +48,13 @@ __device__ __forceinline__ int32_t tabular_reset_state(int32_t start_state, cons
 }
 
 template <int POLICY, bool LDS_TABLE>
-__global__ void __launch_bounds__(kBlock) tabular_step_kernel(StepArgs a) {
+__global__ void __launch_bounds__(kTabularBlock) tabular_step_kernel(StepArgs a) {
   extern __shared__ uint32_t lds_table[];
   const int A = a.table_actions, ncols = A + 1, O = a.table_outcomes;
   const int entries = a.table_states * ncols * O;
   const uint32_t* tab = a.table;
   if (LDS_TABLE) {
-    for (int i = threadIdx.x; i < entries + 8; i += kBlock) lds_table[i] = a.table[i];
+    for (int i = threadIdx.x; i < entries + 8; i += blockDim.x) lds_table[i] = a.table[i];
     __syncthreads();
     tab = lds_table;
   }
@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(kBlock) tabular_step_kernel(StepArgs a) {
   StatAcc acc;
 
   const uint64_t nquads = (a.num_envs + 3) >> 2;
-  for (uint64_t it = (uint64_t)blockIdx.x * kBlock + threadIdx.x; it < nquads; it += (uint64_t)gridDim.x * kBlock) {
+  for (uint64_t it = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; it < nquads; it += (uint64_t)gridDim.x * blockDim.x) {
     // alternate launches sweep in opposite directions (memory-side cache reuse across steps)
     const uint64_t q = a.reverse ? nquads - 1 - it : it;
     int32_t st[4], steps[4], ep_ret[4] = {}, ep_len[4] = {};
@@ -142,14 +142,14 @@ __global__ void __launch_bounds__(kBlock) tabular_step_kernel(StepArgs a) {
 
 // DummyEnv.cs:23-30: state += action; reward = state; done = state >= 10.
 template <int POLICY>
-__global__ void __launch_bounds__(kBlock) dummy_step_kernel(StepArgs a) {
+__global__ void __launch_bounds__(kTabularBlock) dummy_step_kernel(StepArgs a) {
   const bool autoreset = (a.flags & GX_AUTORESET) != 0;
   const bool record = (a.flags & GX_RECORD_STATS) != 0;
   int32_t* const state_row = a.state_int;
   int32_t* const steps_row = a.state_int + a.stride;
   StatAcc acc;
   const uint64_t nquads = (a.num_envs + 3) >> 2;
-  for (uint64_t it = (uint64_t)blockIdx.x * kBlock + threadIdx.x; it < nquads; it += (uint64_t)gridDim.x * kBlock) {
+  for (uint64_t it = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; it < nquads; it += (uint64_t)gridDim.x * blockDim.x) {
     // alternate launches sweep in opposite directions (memory-side cache reuse across steps)
     const uint64_t q = a.reverse ? nquads - 1 - it : it;
     int32_t st[4], steps[4], ep_ret[4] = {}, ep_len[4] = {};
@@ -207,10 +207,10 @@ __global__ void __launch_bounds__(kBlock) dummy_step_kernel(StepArgs a) {
   if (record) block_commit_stats(acc, a.stat_slots);
 }
 
-__global__ void __launch_bounds__(kBlock) tabular_reset_kernel(StepArgs a) {
+__global__ void __launch_bounds__(kTabularBlock) tabular_reset_kernel(StepArgs a) {
   const RngKey key = make_key(a.seed_lo, a.seed_hi, a.tick);
   const uint64_t nquads = (a.num_envs + 3) >> 2;
-  for (uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q < nquads; q += (uint64_t)gridDim.x * kBlock) {
+  for (uint64_t q = (uint64_t)blockIdx.x * kTabularBlock + threadIdx.x; q < nquads; q += (uint64_t)gridDim.x * kTabularBlock) {
     int32_t st[4], zero[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int j = 0; j < 4; j++) st[j] = tabular_reset_state(a.start_state, key, a.env_index_base + q * 4 + j);
@@ -219,39 +219,39 @@ __global__ void __launch_bounds__(kBlock) tabular_reset_kernel(StepArgs a) {
   }
 }
 
-__global__ void __launch_bounds__(kBlock) tabular_sample_kernel(StepArgs a, int32_t nact, int32_t* out) {
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < a.num_envs; i += (uint64_t)gridDim.x * kBlock)
+__global__ void __launch_bounds__(kTabularBlock) tabular_sample_kernel(StepArgs a, int32_t nact, int32_t* out) {
+  for (uint64_t i = (uint64_t)blockIdx.x * kTabularBlock + threadIdx.x; i < a.num_envs; i += (uint64_t)gridDim.x * kTabularBlock)
     out[i] = word_below(policy_word(policy_block(a.seed_lo, a.seed_hi, a.tick, a.env_index_base + i), a.tick), nact);
 }
 
-hipError_t launch_tabular_step(int env_id, const StepArgs& a, int policy, dim3 grid, size_t lds_bytes, hipStream_t stream) {
+hipError_t launch_tabular_step(int env_id, const StepArgs& a, int policy, dim3 grid, int block, size_t lds_bytes, hipStream_t stream) {
   if (env_id == GX_ENV_DUMMY) {
     if (policy == GX_POLICY_RANDOM)
-      hipLaunchKernelGGL(dummy_step_kernel<GX_POLICY_RANDOM>, grid, dim3(kBlock), 0, stream, a);
+      hipLaunchKernelGGL(dummy_step_kernel<GX_POLICY_RANDOM>, grid, dim3(block), 0, stream, a);
     else
-      hipLaunchKernelGGL(dummy_step_kernel<GX_POLICY_DEVICE_ACTIONS>, grid, dim3(kBlock), 0, stream, a);
+      hipLaunchKernelGGL(dummy_step_kernel<GX_POLICY_DEVICE_ACTIONS>, grid, dim3(block), 0, stream, a);
     return hipGetLastError();
   }
   const bool lds = lds_bytes > 0;
   if (policy == GX_POLICY_RANDOM) {
-    if (lds) hipLaunchKernelGGL((tabular_step_kernel<GX_POLICY_RANDOM, true>), grid, dim3(kBlock), lds_bytes, stream, a);
-    else hipLaunchKernelGGL((tabular_step_kernel<GX_POLICY_RANDOM, false>), grid, dim3(kBlock), 0, stream, a);
+    if (lds) hipLaunchKernelGGL((tabular_step_kernel<GX_POLICY_RANDOM, true>), grid, dim3(block), lds_bytes, stream, a);
+    else hipLaunchKernelGGL((tabular_step_kernel<GX_POLICY_RANDOM, false>), grid, dim3(block), 0, stream, a);
   } else {
-    if (lds) hipLaunchKernelGGL((tabular_step_kernel<GX_POLICY_DEVICE_ACTIONS, true>), grid, dim3(kBlock), lds_bytes, stream, a);
-    else hipLaunchKernelGGL((tabular_step_kernel<GX_POLICY_DEVICE_ACTIONS, false>), grid, dim3(kBlock), 0, stream, a);
+    if (lds) hipLaunchKernelGGL((tabular_step_kernel<GX_POLICY_DEVICE_ACTIONS, true>), grid, dim3(block), lds_bytes, stream, a);
+    else hipLaunchKernelGGL((tabular_step_kernel<GX_POLICY_DEVICE_ACTIONS, false>), grid, dim3(block), 0, stream, a);
   }
   return hipGetLastError();
 }
 
 hipError_t launch_tabular_reset(int env_id, const StepArgs& a, dim3 grid, hipStream_t stream) {
   (void)env_id;
-  hipLaunchKernelGGL(tabular_reset_kernel, grid, dim3(kBlock), 0, stream, a);
+  hipLaunchKernelGGL(tabular_reset_kernel, grid, dim3(kTabularBlock), 0, stream, a);
   return hipGetLastError();
 }
 
 hipError_t launch_tabular_sample(int env_id, const StepArgs& a, void* out, dim3 grid, hipStream_t stream) {
   const int nact = env_id == GX_ENV_DUMMY ? 3 : a.table_actions;
-  hipLaunchKernelGGL(tabular_sample_kernel, grid, dim3(kBlock), 0, stream, a, nact, static_cast<int32_t*>(out));
+  hipLaunchKernelGGL(tabular_sample_kernel, grid, dim3(kTabularBlock), 0, stream, a, nact, static_cast<int32_t*>(out));
   return hipGetLastError();
 }
 
