@@ -52,6 +52,8 @@ B_ALG = {
     "breakout": 72 + 72 + 4 + 4 + 4 + 4 + 1 + 100800,      # 100961
     "spaceinvaders": 140 + 140 + 4 + 4 + 4 + 4 + 1 + 100800,  # 101097
 }
+# binary64 mode: the state rows double in width (read + write), nothing else changes
+B_ALG_FP64_EXTRA = {"cartpole": 32, "mountaincar": 16, "mountaincarcontinuous": 16, "pendulum": 24, "acrobot": 48}
 ENV_IDS = {"cartpole": L.ENV_CARTPOLE, "mountaincar": L.ENV_MOUNTAINCAR, "acrobot": L.ENV_ACROBOT,
            "mountaincarcontinuous": L.ENV_MOUNTAINCAR_CONT, "taxi": L.ENV_TAXI,
            "pendulum": L.ENV_PENDULUM, "frozenlake": L.ENV_FROZENLAKE, "pong": L.ENV_PONG, "breakout": L.ENV_BREAKOUT,
@@ -157,7 +159,7 @@ def main():
     ap.add_argument("--env", default="cartpole", choices=sorted(ENV_IDS))
     ap.add_argument("--num-envs", type=int, default=0, help="envs per GPU (default 16 Mi; Pong, Breakout 65536)")
     ap.add_argument("--policy", default="device", choices=["device", "random"])
-    ap.add_argument("--mode", default="exact", choices=["exact", "fast32"])
+    ap.add_argument("--mode", default="exact", choices=["exact", "fast32", "fp64"])
     ap.add_argument("--map", default=None, help="FrozenLake only: '8x8' or rows joined by '/'")
     ap.add_argument("--slippery", action="store_true", help="FrozenLake only: the is_slippery extension")
     ap.add_argument("--taxi-full", action="store_true", help="Taxi only: upstream Taxi-v3 dynamics (extension)")
@@ -212,7 +214,8 @@ def main():
     k_roll = max(1, args.rollout)
     if k_roll > 1:
         args.policy = "random"
-    mode = L.MODE_EXACT if args.mode == "exact" else L.MODE_FAST32
+    mode = {"exact": L.MODE_EXACT, "fast32": L.MODE_FAST32, "fp64": L.MODE_FP64}[args.mode]
+    fp64_state = args.mode == "fp64" and args.env in B_ALG_FP64_EXTRA
     # weak scaling: every rank owns n envs of the n * world batch, keyed by global env index
     base, n_local = shard(n * world, rank, world)
     assert n_local == n
@@ -246,6 +249,8 @@ def main():
         b_alg = 32 + 32 + 4 + 4 + 4 + 1 + 24
     else:
         b_alg = B_ALG[args.env] - (4 if args.policy == "random" else 0) + (8 if args.taxi_full else 0)
+        if fp64_state:
+            b_alg += B_ALG_FP64_EXTRA[args.env]
     achieved = b_alg * n / (kernel_ms * 1e-3) / 1e9
     if k_roll > 1:
         kind = "fused %d-step rollout kernel (one launch per timed step)" % k_roll
@@ -257,7 +262,7 @@ def main():
         "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f64" if args.rk4 else "u8" if args.env in FRAME_ENVS else ("i32" if args.env == "frozenlake" else "f32"),
+        "dtype": "f64" if args.rk4 or fp64_state else "u8" if args.env in FRAME_ENVS else ("i32" if args.env == "frozenlake" else "f32"),
         "data": "synthetic",
         "config": {
             "workload": "%s VectorEnv.Step, %d envs/GPU, %s, auto-reset + RecordEpisodeStatistics fused, "

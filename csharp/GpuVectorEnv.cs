@@ -30,6 +30,10 @@ public sealed unsafe class GpuVectorEnv<TState, TAction> : IDisposable where TAc
                         GxFlags flags = GxFlags.None, int timeLimit = 0, GxMode mode = GxMode.Exact,
                         int device = 0, ulong envIndexBase = 0, string? mapRows = null)
     {
+        // the reference's TState types are float-valued (Env.cs:7); binary64 batches are driven through the
+        // raw entry points (gx_vec_step_device / gx_vec_device_view) by callers that hold doubles
+        if (mode == GxMode.Fp64 && env <= GxEnvId.Acrobot)
+            throw new NotSupportedException("GxMode.Fp64 observations are double; this facade materialises the reference's float states");
         _ctx = ContextHandle.Create(device);
         _stateOf = stateOf;
         _timeLimit = timeLimit;

@@ -17,7 +17,7 @@ public enum GxEnvId
     FrozenLake = 5, Taxi = 6, CliffWalking = 7, Pong = 8, Dummy = 9, Breakout = 10, SpaceInvaders = 11
 }
 
-public enum GxMode { Exact = 0, Fast32 = 1 }
+public enum GxMode { Exact = 0, Fast32 = 1, Fp64 = 2 }
 
 [Flags]
 public enum GxFlags : uint { None = 0, AutoReset = 1, RecordStats = 2, Slippery = 4, TaxiFull = 8, AcrobotRk4 = 16 }

@@ -53,14 +53,8 @@ struct Acrobot64 {
     derive(s);
   }
 
-  // 1/x to the last place or two: hardware estimate plus two Newton steps (this extension is
-  // held to 1e-9 relative, so a correctly rounded divide is not needed)
-  static __device__ __forceinline__ double recip(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    r = fma(fma(-x, r, 1.0), r, r);
-    r = fma(fma(-x, r, 1.0), r, r);
-    return r;
-  }
+  // this extension is held to 1e-9 relative, so a correctly rounded divide is not needed
+  static __device__ __forceinline__ double recip(double x) { return math::rcp64(x); }
 
   // Derivative of (theta1, theta2, dtheta1, dtheta2).  Two sincos per evaluation: the book
   // equations' cos(theta1 - pi/2) is sin(theta1) and cos(theta1 + theta2 - pi/2) is
@@ -146,7 +140,7 @@ struct Acrobot64 {
 };
 
 hipError_t launch_acrobot64_step(const StepArgs& a, int policy, bool fused, dim3 grid, hipStream_t stream) {
-  return launch_step_env<Acrobot64>(a, GX_MODE_EXACT, policy, fused, true, grid, stream);
+  return launch_step_env_exact<Acrobot64>(a, policy, fused, true, grid, stream);
 }
 hipError_t launch_acrobot64_reset(const StepArgs& a, int only_observe, dim3 grid, hipStream_t stream) {
   return launch_reset_env<Acrobot64>(a, only_observe, grid, stream);

@@ -61,6 +61,7 @@ struct gx_vec {
   int envs_per_lane = 4;
   int block = 256;  // threads per workgroup of this batch's step kernels
   bool is_classic = false, is_tabular = false, is_frame = false, is_acrobot64 = false;  // is_frame: Pong, Breakout, SpaceInvaders
+  bool is_classic64 = false;  // GX_MODE_FP64 on one of the five classic-control envs
   bool ep_return_f64 = false;
   // device memory
   void* d_real = nullptr;
@@ -379,6 +380,7 @@ void fill_info(gx_vec* v) {
       in.action_n = 6; in.obs_is_state = 0;
       break;
   }
+  if (v->is_classic64) in.real_dtype = in.obs_dtype = GX_F64;  // the observation is the binary64 state image
   in.state_bytes = v->n * ((uint64_t)in.n_real * dtype_size(in.real_dtype) + (uint64_t)in.n_int * 4);
   in.obs_bytes = v->n * (uint64_t)in.obs_dim * dtype_size(in.obs_dtype);
 }
@@ -448,6 +450,7 @@ int launch_step(gx_vec* v, const void* d_actions, int k_steps, uint64_t action_s
   const bool fused = (v->desc.flags & both) == both && v->desc.time_limit == 0;
   const bool bounded = (v->desc.flags & GX_AUTORESET) && !v->state_dirty;
   if (v->is_acrobot64) e = launch_acrobot64_step(a, policy, fused, v->grid, stream);
+  else if (v->is_classic64) e = launch_classic64_step(v->desc.env_id, a, policy, fused, bounded, v->grid, stream);
   else if (v->is_classic) e = launch_classic_step(v->desc.env_id, a, v->desc.mode, policy, fused, bounded, v->grid, stream);
   else if (v->is_tabular) e = launch_tabular_step(v->desc.env_id, a, policy, v->grid, v->block, v->table_lds_bytes, stream);
   else {
@@ -469,6 +472,7 @@ int launch_sample(gx_vec* v, uint64_t tick, void* d_out, hipStream_t stream) {
   dim3 grid((unsigned)std::min<uint64_t>(blocks ? blocks : 1, (uint64_t)v->ctx->num_cus * 8));
   hipError_t e;
   if (v->is_acrobot64) e = launch_acrobot64_sample(a, d_out, grid, stream);
+  else if (v->is_classic64) e = launch_classic64_sample(v->desc.env_id, a, d_out, grid, stream);
   else if (v->is_classic) e = launch_classic_sample(v->desc.env_id, a, d_out, grid, stream);
   else if (v->is_tabular) e = launch_tabular_sample(v->desc.env_id, a, d_out, grid, stream);
   else if (v->desc.env_id == GX_ENV_PONG) e = launch_pong_sample(a, d_out, grid, stream);
@@ -515,7 +519,7 @@ extern "C" int gx_vec_create(gx_ctx* ctx, const gx_desc* desc, gx_vec** out) {
   if (desc->env_id < 0 || desc->env_id >= GX_ENV_COUNT) return fail(GX_ERR_INVALID, "gx_vec_create: unknown env id %d", desc->env_id);
   if (desc->num_envs == 0) return fail(GX_ERR_INVALID, "gx_vec_create: num_envs must be positive");
   if (desc->num_envs > (1ull << 31)) return fail(GX_ERR_UNSUPPORTED, "gx_vec_create: more than 2^31 envs per batch");
-  if (desc->mode != GX_MODE_EXACT && desc->mode != GX_MODE_FAST32) return fail(GX_ERR_INVALID, "gx_vec_create: unknown mode %d", desc->mode);
+  if (desc->mode != GX_MODE_EXACT && desc->mode != GX_MODE_FAST32 && desc->mode != GX_MODE_FP64) return fail(GX_ERR_INVALID, "gx_vec_create: unknown mode %d", desc->mode);
   if (desc->time_limit < 0) return fail(GX_ERR_INVALID, "gx_vec_create: negative time_limit");
   const uint32_t known = GX_AUTORESET | GX_RECORD_STATS | GX_SLIPPERY | GX_TAXI_FULL | GX_ACROBOT_RK4;
   if (desc->flags & ~known) return fail(GX_ERR_INVALID, "gx_vec_create: unknown flag bits 0x%x", desc->flags & ~known);
@@ -531,9 +535,10 @@ extern "C" int gx_vec_create(gx_ctx* ctx, const gx_desc* desc, gx_vec** out) {
   const int env = desc->env_id;
   v->is_acrobot64 = env == GX_ENV_ACROBOT && (desc->flags & GX_ACROBOT_RK4);
   v->is_classic = env <= GX_ENV_ACROBOT;
+  v->is_classic64 = v->is_classic && !v->is_acrobot64 && desc->mode == GX_MODE_FP64;
   v->is_tabular = env == GX_ENV_FROZENLAKE || env == GX_ENV_TAXI || env == GX_ENV_CLIFFWALKING || env == GX_ENV_DUMMY;
   v->is_frame = env == GX_ENV_PONG || env == GX_ENV_BREAKOUT || env == GX_ENV_SPACEINVADERS;
-  v->envs_per_lane = v->is_acrobot64 ? 2 : (v->is_frame ? 1 : 4);
+  v->envs_per_lane = (v->is_acrobot64 || v->is_classic64) ? 2 : (v->is_frame ? 1 : 4);
   v->stride = (v->n + 3) & ~3ull;  // rows stay 16-byte aligned for every element width
   v->ep_return_f64 = env == GX_ENV_MOUNTAINCAR_CONT || env == GX_ENV_PENDULUM;
   fill_info(v);
@@ -670,6 +675,7 @@ extern "C" int gx_vec_reset(gx_vec* v) {
   }
   hipError_t e;
   if (v->is_acrobot64) e = launch_acrobot64_reset(a, 0, v->grid, c->compute);
+  else if (v->is_classic64) e = launch_classic64_reset(v->desc.env_id, a, v->grid, c->compute);
   else if (v->is_classic) e = launch_classic_reset(v->desc.env_id, a, v->grid, c->compute);
   else if (v->is_tabular) e = launch_tabular_reset(v->desc.env_id, a, v->grid, c->compute);
   else {
@@ -741,7 +747,7 @@ static int copy_obs(gx_vec* v, void* host, hipStream_t stream) {
     return GX_OK;
   }
   const void* src = v->is_acrobot64 ? (const void*)v->d_obs : (const void*)v->d_real;
-  return copy_rows(host, src, 4, in.obs_dim, v->n, v->n, v->stride, hipMemcpyDeviceToHost, stream);
+  return copy_rows(host, src, dtype_size(in.obs_dtype), in.obs_dim, v->n, v->n, v->stride, hipMemcpyDeviceToHost, stream);
 }
 
 extern "C" int gx_vec_get_obs(gx_vec* v, void* host, size_t bytes) {

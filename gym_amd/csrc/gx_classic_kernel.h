@@ -394,6 +394,14 @@ static hipError_t launch_step_env(const StepArgs& a, int mode, int policy, bool 
   return hipGetLastError();
 }
 
+// envs that exist in one numeric form only (the binary64 ones)
+template <class E>
+static hipError_t launch_step_env_exact(const StepArgs& a, int policy, bool fused, bool bounded, dim3 grid, hipStream_t stream) {
+  if (policy == GX_POLICY_RANDOM) launch_step_variant<E, GX_MODE_EXACT, GX_POLICY_RANDOM>(a, fused, bounded, grid, stream);
+  else launch_step_variant<E, GX_MODE_EXACT, GX_POLICY_DEVICE_ACTIONS>(a, fused, bounded, grid, stream);
+  return hipGetLastError();
+}
+
 template <class E>
 static hipError_t launch_reset_env(const StepArgs& a, int only_observe, dim3 grid, hipStream_t stream) {
   hipLaunchKernelGGL(classic_reset_kernel<E>, grid, dim3(kClassicBlock), 0, stream, a, only_observe);

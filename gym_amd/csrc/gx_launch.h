@@ -15,6 +15,12 @@ hipError_t launch_classic_step(int env_id, const StepArgs& a, int mode, int poli
 hipError_t launch_classic_reset(int env_id, const StepArgs& a, dim3 grid, hipStream_t stream);
 hipError_t launch_classic_sample(int env_id, const StepArgs& a, void* out, dim3 grid, hipStream_t stream);
 
+// the same five envs in binary64, GX_MODE_FP64 (gx_classic64.hip)
+hipError_t launch_classic64_step(int env_id, const StepArgs& a, int policy, bool fused, bool bounded, dim3 grid,
+                                 hipStream_t stream);
+hipError_t launch_classic64_reset(int env_id, const StepArgs& a, dim3 grid, hipStream_t stream);
+hipError_t launch_classic64_sample(int env_id, const StepArgs& a, void* out, dim3 grid, hipStream_t stream);
+
 // Acrobot, RK4 in binary64 (gx_acrobot64.hip)
 hipError_t launch_acrobot64_step(const StepArgs& a, int policy, bool fused, dim3 grid, hipStream_t stream);
 hipError_t launch_acrobot64_reset(const StepArgs& a, int only_observe, dim3 grid, hipStream_t stream);

@@ -133,6 +133,19 @@ GX_HD void sincos_reduced(double x, double& s, double& c) {
   quadrant((int)fn, sn, cs, s, c);
 }
 
+// 1 / x in binary64 to the last place or two (hardware estimate plus two Newton steps), for the
+// binary64 dynamics, which are held to a relative tolerance and need no correctly rounded divide.
+GX_HD double rcp64(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+#else
+  return 1.0 / x;
+#endif
+}
+
 // ---- binary32 routines of the FAST32 mode (held to 1e-5 relative, not to the last bit) ----
 
 // sin(x) and cos(x) in binary32 for |x| up to a few thousand, absolute error about 1e-7:

@@ -65,7 +65,12 @@ typedef enum gx_env_id {
 typedef enum gx_mode {
   GX_MODE_EXACT = 0,  /* operation-for-operation binary32 as the C# source; sin/cos/atan2 in
                          binary64 rounded once, no contraction (default) */
-  GX_MODE_FAST32 = 1  /* binary32 device trig, fused multiply-add allowed */
+  GX_MODE_FAST32 = 1, /* binary32 device trig, fused multiply-add allowed */
+  GX_MODE_FP64 = 2    /* extension: the same formulas with every float read as double (state rows,
+                         observation and arithmetic in binary64; actions and rewards keep their
+                         types).  The reference has no such form: parity is against a CPU build of
+                         the same formulas, to 1e-9 relative per step.  Ignored by the tabular and
+                         frame envs and by GX_ACROBOT_RK4, which is binary64 already. */
 } gx_mode;
 
 typedef enum gx_flags {
@@ -117,7 +122,8 @@ typedef struct gx_info {
   int32_t real_dtype;      /* GX_F32 or GX_F64 */
   int32_t n_int;           /* int32 state components, the last is the step counter */
   int32_t obs_dim;         /* elements per env in the observation */
-  int32_t obs_dtype;       /* GX_F32 (classic control), GX_I32 (tabular), GX_U8 (Pong, Breakout, SpaceInvaders) */
+  int32_t obs_dtype;       /* GX_F32 (classic control; GX_F64 under GX_MODE_FP64), GX_I32 (tabular),
+                              GX_U8 (Pong, Breakout, SpaceInvaders) */
   int32_t action_dtype;    /* GX_I32 (Discrete) or GX_F32 (Box of dimension 1) */
   int32_t action_n;        /* Discrete.N, or 0 for Box */
   float action_low, action_high; /* Box bounds when action_dtype == GX_F32 */
@@ -181,6 +187,7 @@ int gx_vec_reset(gx_vec* vec);
  *   CartPole   x, xDot, theta, thetaDot | steps          MountainCar(+Cont)  position, velocity | steps
  *   Pendulum   cos, sin, thetaDot | steps                Acrobot  cos1, sin1, cos2, sin2, thetaDot1, thetaDot2 | steps
  *   Acrobot+RK4 (f64) theta1, theta2, dtheta1, dtheta2 | steps
+ *   (the five above hold doubles under GX_MODE_FP64)
  *   tabular, Dummy   - | state, steps
  *   Pong (f64)     ballX, ballY, ballVelX, ballVelY, leftPaddleY, rightPaddleY | leftScore, rightScore, steps
  *   Breakout (f64) ballX, ballY, ballVelX, ballVelY, paddleX | score, lives, ballStuck,
@@ -193,7 +200,7 @@ int gx_vec_reset(gx_vec* vec);
 int gx_vec_get_state(gx_vec* vec, void* host_soa, size_t bytes);
 int gx_vec_set_state(gx_vec* vec, const void* host_soa, size_t bytes);
 /* Observation of every env as Reset()/Step() would return it: classic control
- * float[obs_dim][num_envs]; tabular int32[num_envs]; Pong, Breakout and SpaceInvaders uint8[num_envs][100800].
+ * float[obs_dim][num_envs] (double under GX_MODE_FP64); tabular int32[num_envs]; Pong, Breakout and SpaceInvaders uint8[num_envs][100800].
  * Synchronous. */
 int gx_vec_get_obs(gx_vec* vec, void* host_obs, size_t bytes);
 

@@ -361,6 +361,9 @@ class VectorEnv {
   using Elem = typename detail::StateOf<State>::Elem;
 
   explicit VectorEnv(uint64_t num_envs, const BatchOptions& o = {}) : batch_(E::kEnvId, num_envs, o), opts_(o) {
+    // the reference's state types are float-valued; a binary64 batch is driven through Batch directly
+    if (batch_.info().obs_dtype == GX_F64)
+      throw std::invalid_argument("VectorEnv materialises float states; use gymx::Batch for GX_MODE_FP64");
     obs_.resize(batch_.info().obs_bytes / sizeof(Elem));
     reward_f_.resize(num_envs);
     reward_d_.resize(num_envs);

@@ -529,6 +529,242 @@ static void acrobot64_import(env_obj* e, const void* reals, const int32_t* ints)
 }
 static const env_vtbl acrobot64_vt = {acrobot64_reset, acrobot64_step, acrobot64_export, acrobot64_import, sizeof(acrobot64_t)};
 
+/* ------------------------------- classic control in binary64 (GXO_FP64)
+ * EXTENSION (parity unpinned by the reference, which computes in binary32):
+ * the same five sources with every `float` read as `double`, every literal
+ * taken at its binary64 value and the (float) casts dropped; statement and
+ * operand order as in the source.  Reset formulas are the source's double
+ * expressions without the final rounding to float. */
+typedef struct {
+  env_obj base;
+  double s[6];
+  int32_t steps;
+  int n; /* components in use, set at creation */
+} classic64_t;
+
+/* Math.Sin and Math.Cos are separate calls into the C library; kept out of line so the compiler
+ * does not merge a sin/cos pair of one argument into sincos(), whose results differ from theirs
+ * in the last place for about one argument in 700 (glibc 2.35). */
+static double __attribute__((noinline)) libm_sin(double x) { return sin(x); }
+static double __attribute__((noinline)) libm_cos(double x) { return cos(x); }
+
+static inline double clampd(double v, double lo, double hi) {
+  if (v < lo) return lo;
+  if (v > hi) return hi;
+  return v;
+}
+
+static void classic64_export(const env_obj* e, void* reals, int32_t* ints) {
+  const classic64_t* c = (const classic64_t*)e;
+  memcpy(reals, c->s, sizeof(double) * (size_t)c->n);
+  ints[0] = c->steps;
+}
+static void classic64_import(env_obj* e, const void* reals, const int32_t* ints) {
+  classic64_t* c = (classic64_t*)e;
+  memcpy(c->s, reals, sizeof(double) * (size_t)c->n);
+  c->steps = ints[0];
+}
+
+/* Envs.CartPole.cs:22-32 */
+static void cartpole64_reset(env_obj* e, const rng_ctx* r) {
+  classic64_t* c = (classic64_t*)e;
+  for (uint32_t i = 0; i < 4; i++) c->s[i] = gxo_rng_uniform(r->seed, r->env_index, r->tick, 0, i) * 0.1 - 0.05;
+  c->steps = 0;
+}
+
+/* Envs.CartPole.cs:34-75 */
+static int cartpole64_step(env_obj* e, const void* action, const rng_ctx* r, double* reward, int* done) {
+  (void)r;
+  classic64_t* c = (classic64_t*)e;
+  int a = *(const int32_t*)action;
+  const double gravity = 9.8, masscart = 1.0, masspole = 0.1;
+  const double total_mass = masscart + masspole;
+  const double length = 0.5;
+  const double polemass_length = masspole * length;
+  const double force_mag = 10.0, tau = 0.02;
+  const double theta_threshold_radians = 12 * M_PI / 180;
+  const double x_threshold = 2.4;
+
+  double x = c->s[0], xDot = c->s[1], theta = c->s[2], thetaDot = c->s[3];
+  double force = a == 1 ? force_mag : -force_mag;
+  double costheta = libm_cos(theta);
+  double sintheta = libm_sin(theta);
+
+  double temp = (force + polemass_length * thetaDot * thetaDot * sintheta) / total_mass;
+  double thetaacc = (gravity * sintheta - costheta * temp) /
+                    (length * (4.0 / 3.0 - masspole * costheta * costheta / total_mass));
+  double xacc = temp - polemass_length * thetaacc * costheta / total_mass;
+
+  x += tau * xDot;
+  xDot += tau * xacc;
+  theta += tau * thetaDot;
+  thetaDot += tau * thetaacc;
+  c->s[0] = x; c->s[1] = xDot; c->s[2] = theta; c->s[3] = thetaDot;
+  c->steps++;
+
+  int d = x < -x_threshold || x > x_threshold || theta < -theta_threshold_radians ||
+          theta > theta_threshold_radians || c->steps >= 500;
+  *done = d;
+  *reward = !d ? 1.0 : 0.0;
+  return 0;
+}
+
+/* Envs.MountainCar.cs:22-30, Envs.MountainCarContinuous.cs:19-27 */
+static void mcar64_reset(env_obj* e, const rng_ctx* r) {
+  classic64_t* c = (classic64_t*)e;
+  c->s[0] = gxo_rng_uniform(r->seed, r->env_index, r->tick, 0, 0) * 0.2 - 0.6;
+  c->s[1] = 0.0;
+  c->steps = 0;
+}
+
+/* Envs.MountainCar.cs:32-50 */
+static int mcar64_step(env_obj* e, const void* action, const rng_ctx* r, double* reward, int* done) {
+  (void)r;
+  classic64_t* c = (classic64_t*)e;
+  int a = *(const int32_t*)action;
+  double position = c->s[0], velocity = c->s[1];
+  double force = (double)(a - 1);
+  velocity += 0.001 * force - 0.0025 * libm_cos(3 * position);
+  velocity = clampd(velocity, -0.07, 0.07);
+  position += velocity;
+  if (position < -1.2) {
+    position = -1.2;
+    velocity = 0.0;
+  }
+  int d = position >= 0.5;
+  *done = d;
+  *reward = d ? 0.0 : -1.0;
+  c->s[0] = position; c->s[1] = velocity;
+  c->steps++;
+  return 0;
+}
+
+/* Envs.MountainCarContinuous.cs:29-49 */
+static int mcc64_step(env_obj* e, const void* action, const rng_ctx* r, double* reward, int* done) {
+  (void)r;
+  classic64_t* c = (classic64_t*)e;
+  double act = (double)*(const float*)action; /* the action stays a float, as the API has it */
+  double position = c->s[0], velocity = c->s[1];
+  double force = clampd(act, -1.0, 1.0);
+  velocity += force * 0.0015 - 0.0025 * libm_cos(3 * position);
+  velocity = clampd(velocity, -0.07, 0.07);
+  position += velocity;
+  if (position < -1.2) {
+    position = -1.2;
+    velocity = 0.0;
+  }
+  int d = position >= 0.45;
+  double rew = velocity * 0.1;
+  if (d) rew += 100.0;
+  *done = d;
+  *reward = rew;
+  c->s[0] = position; c->s[1] = velocity;
+  c->steps++;
+  return 0;
+}
+
+/* Envs.Pendulum.cs:19-28 */
+static void pendulum64_reset(env_obj* e, const rng_ctx* r) {
+  classic64_t* c = (classic64_t*)e;
+  double theta = gxo_rng_uniform(r->seed, r->env_index, r->tick, 0, 0) * 2 * M_PI - M_PI;
+  double thetaDot = gxo_rng_uniform(r->seed, r->env_index, r->tick, 0, 1) * 1 - 0.5;
+  c->s[0] = libm_cos(theta);
+  c->s[1] = libm_sin(theta);
+  c->s[2] = thetaDot;
+  c->steps = 0;
+}
+
+/* Envs.Pendulum.cs:30-60 */
+static int pendulum64_step(env_obj* e, const void* action, const rng_ctx* r, double* reward, int* done) {
+  (void)r;
+  classic64_t* c = (classic64_t*)e;
+  double act = (double)*(const float*)action;
+  const double max_speed = 8.0, max_torque = 2.0, dt = 0.05, g = 10.0, m = 1.0, l = 1.0;
+
+  double theta = atan2(c->s[1], c->s[0]);
+  double thetaDot = c->s[2];
+  double u = clampd(act, -max_torque, max_torque);
+
+  double new_thetaDot = thetaDot + (-3 * g / (2 * l) * libm_sin(theta + M_PI) + 3.0 / (m * l * l) * u) * dt;
+  new_thetaDot = clampd(new_thetaDot, -max_speed, max_speed);
+  double new_theta = theta + new_thetaDot * dt;
+
+  c->s[0] = libm_cos(new_theta);
+  c->s[1] = libm_sin(new_theta);
+  c->s[2] = new_thetaDot;
+  c->steps++;
+
+  *reward = -(theta * theta + 0.1 * thetaDot * thetaDot + 0.001 * u * u);
+  *done = 0;
+  return 0;
+}
+
+/* Envs.Acrobot.cs:22-28 */
+static void acrobot_e64_reset(env_obj* e, const rng_ctx* r) {
+  classic64_t* c = (classic64_t*)e;
+  for (uint32_t i = 0; i < 6; i++) c->s[i] = gxo_rng_uniform(r->seed, r->env_index, r->tick, 0, i) * 0.1 - 0.05;
+  c->steps = 0;
+}
+
+/* Envs.Acrobot.cs:30-91, semi-implicit Euler */
+static int acrobot_e64_step(env_obj* e, const void* action, const rng_ctx* r, double* reward, int* done) {
+  (void)r;
+  classic64_t* c = (classic64_t*)e;
+  int a = *(const int32_t*)action;
+  const double LINK_LENGTH_1 = 1.0, LINK_LENGTH_2 = 1.0, LINK_MASS_1 = 1.0, LINK_MASS_2 = 1.0;
+  const double LINK_COM_POS_1 = 0.5, LINK_COM_POS_2 = 0.5, LINK_MOI_1 = 1.0, LINK_MOI_2 = 1.0;
+  const double MAX_VEL_1 = 4 * M_PI, MAX_VEL_2 = 9 * M_PI;
+  const double dt = 0.2, g = 9.8;
+  const double torque[3] = {-1.0, 0.0, 1.0};
+  if (a < 0 || a > 2) return -1; /* Envs.Acrobot.cs:51 */
+
+  double theta1 = atan2(c->s[1], c->s[0]);
+  double theta2 = atan2(c->s[3], c->s[2]);
+  double dtheta1 = c->s[4];
+  double dtheta2 = c->s[5];
+  double u = torque[a];
+
+  double d1 = LINK_MASS_1 * LINK_COM_POS_1 * LINK_COM_POS_1 +
+              LINK_MASS_2 * (LINK_LENGTH_1 * LINK_LENGTH_1 + LINK_COM_POS_2 * LINK_COM_POS_2 +
+                             2 * LINK_LENGTH_1 * LINK_COM_POS_2 * libm_cos(theta2)) +
+              LINK_MOI_1 + LINK_MOI_2;
+  double d2 = LINK_MASS_2 * (LINK_COM_POS_2 * LINK_COM_POS_2 + LINK_LENGTH_1 * LINK_COM_POS_2 * libm_cos(theta2)) + LINK_MOI_2;
+  double phi2 = LINK_MASS_2 * LINK_COM_POS_2 * g * libm_cos(theta1 + theta2 - M_PI / 2.0);
+  double phi1 = -LINK_MASS_2 * LINK_LENGTH_1 * LINK_COM_POS_2 * dtheta2 * dtheta2 * libm_sin(theta2) -
+                2 * LINK_MASS_2 * LINK_LENGTH_1 * LINK_COM_POS_2 * dtheta2 * dtheta1 * libm_sin(theta2) +
+                (LINK_MASS_1 * LINK_COM_POS_1 + LINK_MASS_2 * LINK_LENGTH_1) * g * libm_cos(theta1 - M_PI / 2.0) + phi2;
+  double ddtheta2 = (u + d2 / d1 * phi1 - LINK_MASS_2 * LINK_LENGTH_1 * LINK_COM_POS_2 * dtheta1 * dtheta1 * libm_sin(theta2) - phi2) /
+                    (LINK_MASS_2 * LINK_COM_POS_2 * LINK_COM_POS_2 + LINK_MOI_2 - d2 * d2 / d1);
+  double ddtheta1 = -(d2 * ddtheta2 + phi1) / d1;
+
+  dtheta1 += dt * ddtheta1;
+  dtheta2 += dt * ddtheta2;
+  dtheta1 = clampd(dtheta1, -MAX_VEL_1, MAX_VEL_1);
+  dtheta2 = clampd(dtheta2, -MAX_VEL_2, MAX_VEL_2);
+  theta1 += dt * dtheta1;
+  theta2 += dt * dtheta2;
+
+  c->s[0] = libm_cos(theta1);
+  c->s[1] = libm_sin(theta1);
+  c->s[2] = libm_cos(theta2);
+  c->s[3] = libm_sin(theta2);
+  c->s[4] = dtheta1;
+  c->s[5] = dtheta2;
+  c->steps++;
+
+  double tip_y = -LINK_LENGTH_1 * libm_cos(theta1) - LINK_LENGTH_2 * libm_cos(theta1 + theta2);
+  int d = tip_y > 1.0 || c->steps >= 500;
+  *done = d;
+  *reward = d ? 0.0 : -1.0;
+  return 0;
+}
+
+static const env_vtbl cartpole64_vt = {cartpole64_reset, cartpole64_step, classic64_export, classic64_import, sizeof(classic64_t)};
+static const env_vtbl mcar64_vt = {mcar64_reset, mcar64_step, classic64_export, classic64_import, sizeof(classic64_t)};
+static const env_vtbl mcc64_vt = {mcar64_reset, mcc64_step, classic64_export, classic64_import, sizeof(classic64_t)};
+static const env_vtbl pendulum64_vt = {pendulum64_reset, pendulum64_step, classic64_export, classic64_import, sizeof(classic64_t)};
+static const env_vtbl acrobot_e64_vt = {acrobot_e64_reset, acrobot_e64_step, classic64_export, classic64_import, sizeof(classic64_t)};
+
 /* ---------------------------------------------------- grid worlds (tabular) */
 #define GRID_MAX_CELLS 4096
 typedef struct grid_desc {
@@ -1350,7 +1586,7 @@ struct gxo_vec {
   uint64_t tick;
   env_obj** envs;
   grid_desc* grid;
-  int n_real, real_is_f64, n_int, obs_dim, action_is_float;
+  int n_real, real_is_f64, obs_is_f64, n_int, obs_dim, action_is_float;
   /* Wrappers.TimeLimit.cs:9 `_steps` per env */
   int32_t* tl_steps;
   /* EnvWrapper.cs:27-28 `_currentReward`, `_currentLength` per env */
@@ -1418,6 +1654,14 @@ gxo_vec* gxo_vec_create(int env_id, uint64_t num_envs, uint64_t seed, uint32_t f
     case GXO_BREAKOUT: vt = &breakout_vt; v->n_real = 5; v->real_is_f64 = 1; v->n_int = 8; v->obs_dim = GXO_PONG_FRAME_BYTES; break;
     case GXO_SPACEINVADERS: vt = &invaders_vt; v->n_real = 13; v->real_is_f64 = 1; v->n_int = 9; v->obs_dim = GXO_PONG_FRAME_BYTES; break;
   }
+  int classic64 = 0;
+  if ((flags & GXO_FP64) && env_id <= GXO_ACROBOT && !(env_id == GXO_ACROBOT && (flags & GXO_ACROBOT_RK4))) {
+    static const env_vtbl* const vt64[5] = {&cartpole64_vt, &mcar64_vt, &mcc64_vt, &pendulum64_vt, &acrobot_e64_vt};
+    vt = vt64[env_id];
+    v->real_is_f64 = 1;
+    v->obs_is_f64 = 1;
+    classic64 = 1;
+  }
   if (env_id == GXO_FROZENLAKE || env_id == GXO_CLIFFWALKING) {
     grid_desc* g = (grid_desc*)calloc(1, sizeof *g);
     if (env_id == GXO_FROZENLAKE) {
@@ -1443,6 +1687,7 @@ gxo_vec* gxo_vec_create(int env_id, uint64_t num_envs, uint64_t seed, uint32_t f
     e->vt = vt;
     if (v->grid) ((grid_t*)e)->g = v->grid;
     if (env_id == GXO_TAXI) ((taxi_t*)e)->full = (flags & GXO_TAXI_FULL) != 0;
+    if (classic64) ((classic64_t*)e)->n = v->n_real;
     v->envs[i] = e;
   }
   v->tl_steps = (int32_t*)calloc(num_envs ? num_envs : 1, sizeof(int32_t));
@@ -1481,6 +1726,7 @@ uint64_t gxo_vec_num_envs(const gxo_vec* v) { return v->n; } /* VectorEnv.cs:13 
 int gxo_vec_obs_dim(const gxo_vec* v) { return v->obs_dim; }
 int gxo_vec_n_real(const gxo_vec* v) { return v->n_real; }
 int gxo_vec_real_is_f64(const gxo_vec* v) { return v->real_is_f64; }
+int gxo_vec_obs_is_f64(const gxo_vec* v) { return v->obs_is_f64; }
 int gxo_vec_n_int(const gxo_vec* v) { return v->n_int; }
 uint64_t gxo_vec_tick(const gxo_vec* v) { return v->tick; }
 size_t gxo_vec_state_bytes(const gxo_vec* v) {
@@ -1623,7 +1869,7 @@ void gxo_vec_get_obs(const gxo_vec* v, void* buf) {
                           (uint8_t*)buf + (size_t)i * GXO_PONG_FRAME_BYTES);
     } else if (v->env_id == GXO_SPACEINVADERS) {
       gxo_invaders_render(tmp, itmp, (uint8_t*)buf + (size_t)i * GXO_PONG_FRAME_BYTES);
-    } else if (v->env_id == GXO_ACROBOT && v->real_is_f64) {
+    } else if (v->env_id == GXO_ACROBOT && v->real_is_f64 && !v->obs_is_f64) {
       float* o = (float*)buf;
       o[0 * v->n + i] = (float)cos(tmp[0]);
       o[1 * v->n + i] = (float)sin(tmp[0]);
@@ -1631,6 +1877,8 @@ void gxo_vec_get_obs(const gxo_vec* v, void* buf) {
       o[3 * v->n + i] = (float)sin(tmp[1]);
       o[4 * v->n + i] = (float)tmp[2];
       o[5 * v->n + i] = (float)tmp[3];
+    } else if (v->obs_is_f64) {
+      for (int k = 0; k < v->n_real; k++) ((double*)buf)[(size_t)k * v->n + i] = tmp[k];
     } else if (v->n_real > 0) {
       for (int k = 0; k < v->n_real; k++) ((float*)buf)[(size_t)k * v->n + i] = ((float*)tmp)[k];
     } else {

@@ -52,7 +52,9 @@ enum {
   GXO_RECORD_STATS = 2u,  /* EnvWrapper.cs:23-58 RecordEpisodeStatistics */
   GXO_SLIPPERY = 4u,      /* extension: upstream FrozenLake is_slippery */
   GXO_TAXI_FULL = 8u,     /* extension: upstream Taxi-v3 dynamics */
-  GXO_ACROBOT_RK4 = 16u   /* extension: upstream Acrobot (RK4, fp64) */
+  GXO_ACROBOT_RK4 = 16u,  /* extension: upstream Acrobot (RK4, fp64) */
+  GXO_FP64 = 32u          /* extension: the five classic-control envs computed and stored in binary64
+                             (the engine's GX_MODE_FP64) */
 };
 
 #define GXO_PONG_FRAME_BYTES (210 * 160 * 3)
@@ -85,6 +87,7 @@ uint64_t gxo_vec_num_envs(const gxo_vec* v);
 int gxo_vec_obs_dim(const gxo_vec* v);      /* floats per env (Pong: bytes per env) */
 int gxo_vec_n_real(const gxo_vec* v);       /* real-valued state components */
 int gxo_vec_real_is_f64(const gxo_vec* v);
+int gxo_vec_obs_is_f64(const gxo_vec* v);  /* classic control under GXO_FP64: double[obs_dim][N] */
 int gxo_vec_n_int(const gxo_vec* v);        /* int32 state components (last one = steps) */
 size_t gxo_vec_state_bytes(const gxo_vec* v);
 uint64_t gxo_vec_tick(const gxo_vec* v);

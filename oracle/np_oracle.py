@@ -220,6 +220,135 @@ def acrobot_step(s, steps, action):
     return ns, steps, np.where(done, 0.0, -1.0), done
 
 
+# ------------------------------------------- classic control in binary64
+# Extension (the engine's FP64 mode; the reference computes in binary32): the
+# same sources with every float read as double and the (float) casts dropped.
+def _cos(x):
+    return _map1(math.cos, x)
+
+
+def _sin(x):
+    return _map1(math.sin, x)
+
+
+def _atan2(y, x):
+    y = np.asarray(y, f64)
+    x = np.asarray(x, f64)
+    return np.array([math.atan2(float(a), float(b)) for a, b in zip(y.ravel(), x.ravel())], f64).reshape(y.shape)
+
+
+def cartpole64_reset(seed, env, tick):
+    return np.stack([rng_uniform(seed, env, tick, 0, i) * 0.1 - 0.05 for i in range(4)])
+
+
+def cartpole64_step(s, steps, action):
+    """Envs.CartPole.cs:34-75 in double"""
+    total_mass = 1.0 + 0.1
+    pml = 0.1 * 0.5
+    thr = 12 * math.pi / 180
+    x, xd, th, thd = (s[i].astype(f64) for i in range(4))
+    force = np.where(np.asarray(action) == 1, 10.0, -10.0)
+    c, sn = _cos(th), _sin(th)
+    temp = (force + pml * thd * thd * sn) / total_mass
+    thacc = (9.8 * sn - c * temp) / (0.5 * (4.0 / 3.0 - 0.1 * c * c / total_mass))
+    xacc = temp - pml * thacc * c / total_mass
+    x = x + 0.02 * xd
+    xd = xd + 0.02 * xacc
+    th = th + 0.02 * thd
+    thd = thd + 0.02 * thacc
+    steps = steps + 1
+    done = (x < -2.4) | (x > 2.4) | (th < -thr) | (th > thr) | (steps >= 500)
+    return np.stack([x, xd, th, thd]), steps, np.where(done, 0.0, 1.0), done
+
+
+def mountaincar64_reset(seed, env, tick):
+    p = rng_uniform(seed, env, tick, 0, 0) * 0.2 - 0.6
+    return np.stack([p, np.zeros_like(p)])
+
+
+def _mcar64_tail(p, v, goal):
+    v = clamp(v, -0.07, 0.07)
+    p = p + v
+    wall = p < -1.2
+    p = np.where(wall, -1.2, p)
+    v = np.where(wall, 0.0, v)
+    return p, v, p >= goal
+
+
+def mountaincar64_step(s, steps, action):
+    """Envs.MountainCar.cs:32-50 in double"""
+    p, v = s[0].astype(f64), s[1].astype(f64)
+    force = (np.asarray(action, np.int64) - 1).astype(f64)
+    v = v + (0.001 * force - 0.0025 * _cos(3 * p))
+    p, v, done = _mcar64_tail(p, v, 0.5)
+    return np.stack([p, v]), steps + 1, np.where(done, 0.0, -1.0), done
+
+
+def mountaincar_cont64_step(s, steps, action):
+    """Envs.MountainCarContinuous.cs:29-49 in double; the action stays a float"""
+    p, v = s[0].astype(f64), s[1].astype(f64)
+    force = clamp(np.asarray(action, f32).astype(f64), -1.0, 1.0)
+    v = v + (force * 0.0015 - 0.0025 * _cos(3 * p))
+    p, v, done = _mcar64_tail(p, v, 0.45)
+    reward = v * 0.1
+    reward = np.where(done, reward + 100.0, reward)
+    return np.stack([p, v]), steps + 1, reward, done
+
+
+def pendulum64_reset(seed, env, tick):
+    th = rng_uniform(seed, env, tick, 0, 0) * 2 * math.pi - math.pi
+    thd = rng_uniform(seed, env, tick, 0, 1) * 1 - 0.5
+    return np.stack([_cos(th), _sin(th), thd])
+
+
+def pendulum64_step(s, steps, action):
+    """Envs.Pendulum.cs:30-60 in double"""
+    dt = 0.05
+    th = _atan2(s[1], s[0])
+    thd = s[2].astype(f64)
+    u = clamp(np.asarray(action, f32).astype(f64), -2.0, 2.0)
+    nthd = thd + (-3 * 10.0 / (2 * 1.0) * _sin(th + math.pi) + 3.0 / (1.0 * 1.0 * 1.0) * u) * dt
+    nthd = clamp(nthd, -8.0, 8.0)
+    nth = th + nthd * dt
+    reward = -(th * th + 0.1 * thd * thd + 0.001 * u * u)
+    return np.stack([_cos(nth), _sin(nth), nthd]), steps + 1, reward, np.zeros(th.shape, bool)
+
+
+def acrobot64_euler_reset(seed, env, tick):
+    return np.stack([rng_uniform(seed, env, tick, 0, i) * 0.1 - 0.05 for i in range(6)])
+
+
+def acrobot64_euler_step(s, steps, action):
+    """Envs.Acrobot.cs:30-91 in double (semi-implicit Euler, as the reference integrates)"""
+    action = np.asarray(action)
+    if ((action < 0) | (action > 2)).any():
+        raise IndexError("torque[action]")
+    g, dt = 9.8, 0.2
+    mv1, mv2 = 4 * math.pi, 9 * math.pi
+    t1 = _atan2(s[1], s[0])
+    t2 = _atan2(s[3], s[2])
+    w1, w2 = s[4].astype(f64), s[5].astype(f64)
+    u = (action.astype(np.int64) - 1).astype(f64)
+    c2, s2 = _cos(t2), _sin(t2)
+    d1 = 1.0 * 0.5 * 0.5 + 1.0 * (1.0 * 1.0 + 0.5 * 0.5 + 2 * 1.0 * 0.5 * c2) + 1.0 + 1.0
+    d2 = 1.0 * (0.5 * 0.5 + 1.0 * 0.5 * c2) + 1.0
+    phi2 = 1.0 * 0.5 * g * _cos(t1 + t2 - math.pi / 2.0)
+    phi1 = (-1.0 * 1.0 * 0.5 * w2 * w2 * s2 - 2 * 1.0 * 1.0 * 0.5 * w2 * w1 * s2
+            + (1.0 * 0.5 + 1.0 * 1.0) * g * _cos(t1 - math.pi / 2.0) + phi2)
+    a2 = (u + d2 / d1 * phi1 - 1.0 * 1.0 * 0.5 * w1 * w1 * s2 - phi2) / (1.0 * 0.5 * 0.5 + 1.0 - d2 * d2 / d1)
+    a1 = -(d2 * a2 + phi1) / d1
+    w1 = clamp(w1 + dt * a1, -mv1, mv1)
+    w2 = clamp(w2 + dt * a2, -mv2, mv2)
+    t1 = t1 + dt * w1
+    t2 = t2 + dt * w2
+    ct1 = _cos(t1)
+    ns = np.stack([ct1, _sin(t1), _cos(t2), _sin(t2), w1, w2])
+    steps = steps + 1
+    tip = -1.0 * ct1 - 1.0 * _cos(t1 + t2)
+    done = (tip > 1.0) | (steps >= 500)
+    return ns, steps, np.where(done, 0.0, -1.0), done
+
+
 # -------------------------------------------------------------- grid worlds
 def parse_map(rows):
     """Envs.FrozenLake.cs:31-42 -> (nrow, ncol, goal, hole mask)"""

@@ -14,7 +14,7 @@ _SO = os.path.join(_HERE, "_build", "libgym_oracle.so")
 
 (CARTPOLE, MOUNTAINCAR, MOUNTAINCAR_CONT, PENDULUM, ACROBOT, FROZENLAKE, TAXI, CLIFFWALKING, PONG, DUMMY,
  BREAKOUT, SPACEINVADERS) = range(12)
-AUTORESET, RECORD_STATS, SLIPPERY, TAXI_FULL, ACROBOT_RK4 = 1, 2, 4, 8, 16
+AUTORESET, RECORD_STATS, SLIPPERY, TAXI_FULL, ACROBOT_RK4, FP64 = 1, 2, 4, 8, 16, 32
 PONG_FRAME_BYTES = 210 * 160 * 3
 FLOAT_ACTION = {MOUNTAINCAR_CONT, PENDULUM}
 
@@ -69,7 +69,7 @@ def lib():
     for name in ("num_envs", "tick"):
         getattr(L, "gxo_vec_" + name).restype = u64
         getattr(L, "gxo_vec_" + name).argtypes = [vp]
-    for name in ("obs_dim", "n_real", "real_is_f64", "n_int"):
+    for name in ("obs_dim", "n_real", "real_is_f64", "obs_is_f64", "n_int"):
         getattr(L, "gxo_vec_" + name).restype = C.c_int
         getattr(L, "gxo_vec_" + name).argtypes = [vp]
     L.gxo_vec_state_bytes.restype = C.c_size_t
@@ -114,6 +114,7 @@ class OracleVec:
         self.n = num_envs
         self.n_real = L.gxo_vec_n_real(self._h)
         self.real_is_f64 = bool(L.gxo_vec_real_is_f64(self._h))
+        self.obs_is_f64 = bool(L.gxo_vec_obs_is_f64(self._h))
         self.n_int = L.gxo_vec_n_int(self._h)
         self.obs_dim = L.gxo_vec_obs_dim(self._h)
         self.action_dtype = np.float32 if env_id in FLOAT_ACTION else np.int32
@@ -184,7 +185,7 @@ class OracleVec:
         if self.env_id in (PONG, BREAKOUT, SPACEINVADERS):
             out = np.empty((self.n, PONG_FRAME_BYTES), np.uint8)
         elif self.n_real > 0:
-            out = np.empty((self.obs_dim, self.n), np.float32)
+            out = np.empty((self.obs_dim, self.n), np.float64 if self.obs_is_f64 else np.float32)
         else:
             out = np.empty(self.n, np.int32)
         lib().gxo_vec_get_obs(self._h, _ptr(out))

@@ -50,5 +50,6 @@ def make_pair(oracle, env_id, n, seed=1, flags=0, time_limit=0, map_rows=None, b
     o_rows = map_rows
     if map_rows == "8x8":
         o_rows = ["SFFFFFFF", "FFFFFFFF", "FFFHFFFF", "FFFFFHFF", "FFFHFFFF", "FHHFFFHF", "FHFFHFHF", "FFFHFFFG"]
-    o = oracle.OracleVec(env_id, n, seed=seed, flags=flags, time_limit=time_limit, map_rows=o_rows, env_index_base=base)
+    o_flags = flags | (oracle.FP64 if mode == L.MODE_FP64 else 0)  # the oracle spells that mode as a flag
+    o = oracle.OracleVec(env_id, n, seed=seed, flags=o_flags, time_limit=time_limit, map_rows=o_rows, env_index_base=base)
     return g, o

@@ -504,3 +504,86 @@ def test_rccl_stats_allreduce_single_rank(oracle):
     comm.close()
     for f in ("episodes", "sum_return", "sum_length", "sum_return_sq", "min_return", "max_return"):
         assert getattr(s, f) == getattr(local, f) == getattr(so, f), f
+
+
+FP64_TOL = 1e-9  # stated tolerance of the binary64 mode, relative per step (floored at 1e-6 in magnitude)
+
+
+@pytest.mark.parametrize("env_id", CLASSIC)
+def test_fp64_mode_teacher_forced(oracle, env_id):
+    """extension, pinned only by the oracle's own binary64 restatement"""
+    n = 4099  # ragged: not a multiple of the 2-env lane width
+    g, o = make_pair(oracle, env_id, n, seed=23, mode=L.MODE_FP64, base=3)
+    assert g.info.real_dtype == L.F64 and g.info.obs_dtype == L.F64 and g.info.obs_is_state == 1
+    g.reset(); o.reset()
+    gr, gi = g.get_state(); orr, oi = o.get_state()
+    assert gr.dtype == np.float64 and np.array_equal(gi, oi)
+    if env_id != L.ENV_PENDULUM:  # Pendulum's reset takes a cos and a sin
+        assert np.array_equal(bits(gr), bits(orr))
+    assert np.abs(gr - orr).max() <= 1e-15
+    assert np.array_equal(bits(g.get_obs()), bits(gr))
+    g.set_state(orr, oi)
+    rng = np.random.default_rng(env_id)
+    for t in range(40):
+        a = random_actions(rng, env_id, n)
+        obs, rew, done, _ = g.step_host(a, want_obs=True)
+        orew, odone, _ = o.step(a)
+        gr, gi = g.get_state(); orr, oi = o.get_state()
+        err = np.abs(gr - orr) / np.maximum(np.abs(orr), 1e-6)
+        assert err.max() <= FP64_TOL, (t, err.max())
+        assert np.array_equal(gi, oi)
+        assert np.abs(rew.astype(np.float64) - orew).max() <= FP64_TOL * max(1.0, np.abs(orew).max())
+        assert np.array_equal(done, odone)
+        assert obs.dtype == np.float64 and np.array_equal(bits(obs), bits(gr))
+        g.set_state(orr, oi)
+
+
+@pytest.mark.parametrize("env_id", CLASSIC)
+def test_fp64_mode_fused_autoreset_statistics(oracle, env_id):
+    """auto-reset + RecordEpisodeStatistics in the binary64 kernels (the BOUNDED variants), free-running:
+    short enough that no env sits within rounding of a termination threshold"""
+    n, steps = 2048, 60
+    flags = L.AUTORESET | L.RECORD_STATS
+    g, o = make_pair(oracle, env_id, n, seed=29, flags=flags, mode=L.MODE_FP64)
+    g.reset(); o.reset()
+    rng = np.random.default_rng(50 + env_id)
+    if env_id in (L.ENV_MOUNTAINCAR, L.ENV_MOUNTAINCAR_CONT, L.ENV_ACROBOT):
+        # bring episodes to an end within the run: counters close to the limits, positions near the goal
+        gr, gi = o.get_state()
+        gr = gr.copy(); gi = gi.copy()
+        if env_id == L.ENV_ACROBOT:
+            gi[0] = rng.integers(440, 500, n)
+        else:
+            gr[0] = rng.uniform(0.3, 0.5, n); gr[1] = 0.06
+        g.set_state(gr, gi); o.set_state(gr, gi)
+    for t in range(steps):
+        a = random_actions(rng, env_id, n)
+        _, rew, done, _ = g.step_host(a)
+        orew, odone, _ = o.step(a)
+        assert np.array_equal(done, odone), t
+        gr, gi = g.get_state(); orr, oi = o.get_state()
+        assert np.array_equal(gi, oi), t
+        err = np.abs(gr - orr) / np.maximum(np.abs(orr), 1e-3)
+        assert err.max() <= 1e-7, (t, err.max())  # free-running: rounding differences compound
+    s, so = g.stats(), o.stats()
+    assert s.episodes == so.episodes and s.sum_length == so.sum_length
+    if env_id != L.ENV_PENDULUM:
+        assert so.episodes > 0
+    assert abs(s.sum_return - so.sum_return) <= 1e-9 * max(1.0, abs(so.sum_return))
+
+
+def test_fp64_mode_rollout_matches_single_steps(oracle):
+    """K fused steps == K single steps, bit for bit, with the in-kernel policy"""
+    n = 3000
+    for env_id in CLASSIC:
+        flags = L.AUTORESET | L.RECORD_STATS
+        a, _ = make_pair(oracle, env_id, n, seed=31, flags=flags, mode=L.MODE_FP64)
+        b, _ = make_pair(oracle, env_id, n, seed=31, flags=flags, mode=L.MODE_FP64)
+        a.reset(); b.reset()
+        a.rollout(24)
+        for _ in range(24):
+            b.step_random()
+        ar, ai = a.get_state(); br, bi = b.get_state()
+        assert np.array_equal(bits(ar), bits(br)) and np.array_equal(ai, bi), env_id
+        sa, sb = a.stats(), b.stats()
+        assert sa.episodes == sb.episodes and sa.sum_return == sb.sum_return

@@ -70,6 +70,57 @@ def test_classic_control_wide_states(oracle):
         assert np.array_equal(done.astype(bool), done2), name
 
 
+CLASSIC64 = [
+    ("CARTPOLE", NP.cartpole64_reset, NP.cartpole64_step, 2),
+    ("MOUNTAINCAR", NP.mountaincar64_reset, NP.mountaincar64_step, 3),
+    ("MOUNTAINCAR_CONT", NP.mountaincar64_reset, NP.mountaincar_cont64_step, None),
+    ("PENDULUM", NP.pendulum64_reset, NP.pendulum64_step, None),
+    ("ACROBOT", NP.acrobot64_euler_reset, NP.acrobot64_euler_step, 3),
+]
+
+
+@pytest.mark.parametrize("name,resetf,stepf,nact", CLASSIC64, ids=[c[0] for c in CLASSIC64])
+def test_classic_control_binary64_bitwise(oracle, name, resetf, stepf, nact):
+    """the FP64 extension: both restatements run the same libm, so they agree to the bit"""
+    eid = getattr(oracle, name)
+    v = oracle.OracleVec(eid, N, seed=SEED, flags=oracle.FP64, env_index_base=10)
+    assert v.real_is_f64 and v.obs_is_f64
+    v.reset()
+    reals, ints = v.get_state()
+    assert reals.dtype == np.float64
+    assert np.array_equal(bits(reals), bits(resetf(SEED, np.arange(N, dtype=np.uint64) + 10, 0)))
+    assert np.array_equal(bits(v.get_obs()), bits(reals))
+    rng = np.random.default_rng(1)
+    s, st = reals.copy(), ints[0].copy()
+    for t in range(STEPS):
+        a = (rng.random(N) * 6 - 3).astype(np.float32) if nact is None else rng.integers(0, nact, N).astype(np.int32)
+        rew, done, _ = v.step(a)
+        s, st, rew2, done2 = stepf(s, st, a)
+        reals, ints = v.get_state()
+        assert np.array_equal(bits(reals), bits(s)), (name, t)
+        assert np.array_equal(ints[0], st)
+        assert np.array_equal(bits(rew), bits(np.asarray(rew2, np.float64))), (name, t)
+        assert np.array_equal(done.astype(bool), done2)
+
+
+def test_classic_control_binary64_tracks_binary32(oracle):
+    """one step from the same state: the binary64 form stays within binary32 rounding of the reference form"""
+    rng = np.random.default_rng(5)
+    for name, _, _, nact in CLASSIC64:
+        eid = getattr(oracle, name)
+        v32 = oracle.OracleVec(eid, N, seed=3)
+        v64 = oracle.OracleVec(eid, N, seed=3, flags=oracle.FP64)
+        v32.reset(); v64.reset()
+        for t in range(10):
+            r32, i32 = v32.get_state()
+            v64.set_state(r32.astype(np.float64), i32)
+            a = (rng.random(N) * 4 - 2).astype(np.float32) if nact is None else rng.integers(0, nact, N).astype(np.int32)
+            v32.step(a); v64.step(a)
+            r32, _ = v32.get_state(); r64, _ = v64.get_state()
+            err = np.abs(r32.astype(np.float64) - r64) / np.maximum(np.abs(r64), 1e-1)
+            assert err.max() <= 1e-5, (name, t, err.max())
+
+
 def test_grid_worlds_bitwise(oracle):
     rng = np.random.default_rng(3)
     maps = [None, ["SFFFFFFF", "FFFFFFFF", "FFFHFFFF", "FFFFFHFF", "FFFHFFFF", "FHHFFFHF", "FHFFHFHF", "FFFHFFFG"], ["SFG", "HFF"]]
