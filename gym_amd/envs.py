@@ -92,7 +92,7 @@ class _TupleStateEnv(DeviceEnv):
 class _ArrayStateEnv(DeviceEnv):
     def _state_of(self, obs, index=0):
         # a fresh array per call: the reference hands out its internal array (Envs.Pendulum.cs:59)
-        return np.array(obs[:, index], np.float32)
+        return np.array(obs[:, index], obs.dtype)  # float32; float64 in the FP64 mode
 
 
 class _IntStateEnv(DeviceEnv):

@@ -5,7 +5,9 @@ envs, so these fixtures are outputs of the oracle (itself pinned by hand-derived
 and by the independent numpy restatement).  Per env: 256 start states x 64 steps of random
 actions -- initial SoA state, the actions, every reward / done flag and the final state; for
 Pong additionally 8 frames as bit masks (a frame is 0/255 with equal channels), for Breakout
-and SpaceInvaders as indices into a small palette.
+and SpaceInvaders as indices into a small palette.  The binary64 mode (an extension of this
+build) has its own fixtures, *_fp64.npz: 64 envs x 32 steps with the state after every step, so
+that a checker can re-synchronise per step.
 
     python tests/golden/make_golden.py
 """
@@ -43,6 +45,8 @@ CASES = [
     ("breakout", O.BREAKOUT, 4, {}),
     ("spaceinvaders", O.SPACEINVADERS, 6, {}),
 ]
+CASES_FP64 = [("cartpole_fp64", O.CARTPOLE, 2), ("mountaincar_fp64", O.MOUNTAINCAR, 3), ("mountaincar_cont_fp64", O.MOUNTAINCAR_CONT, None),
+              ("pendulum_fp64", O.PENDULUM, None), ("acrobot_fp64", O.ACROBOT, 3)]
 
 
 def main():
@@ -76,5 +80,32 @@ def main():
         print(name, {k: getattr(x, "shape", None) for k, x in out.items()})
 
 
+def main_fp64():
+    n, steps = 64, 32
+    for name, eid, nact in CASES_FP64:
+        rng = np.random.default_rng(sum(map(ord, name)))
+        v = O.OracleVec(eid, n, seed=SEED, flags=O.FP64)
+        v.reset()
+        init = v.get_state_raw().copy()
+        if nact is None:
+            actions = (rng.random((steps, n)) * 5 - 2.5).astype(np.float32)
+        else:
+            actions = rng.integers(0, nact, (steps, n)).astype(np.int32)
+        rewards = np.empty((steps, n), np.float64)
+        dones = np.empty((steps, n), np.uint8)
+        states = []
+        for t in range(steps):
+            rewards[t], dones[t], _ = v.step(actions[t])
+            states.append(v.get_state_raw().copy())
+        out = dict(init=init, actions=actions, rewards=rewards, dones=dones, states=np.stack(states), final=states[-1],
+                   seed=np.int64(SEED))
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print(name, {k: getattr(x, "shape", None) for k, x in out.items()})
+
+
 if __name__ == "__main__":
+    if "--fp64-only" in sys.argv:
+        main_fp64()
+        sys.exit(0)
     main()
+    main_fp64()

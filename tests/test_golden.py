@@ -1,7 +1,9 @@
 """Committed golden vectors (tests/golden/*.npz, made by tests/golden/make_golden.py from the
 oracle): the oracle must keep reproducing them (CPU), and the HIP path must reproduce them
 through the C ABI (GPU) -- bit-exact for tabular envs, Pong and Breakout, and for the continuous envs too
-unless a last-place double-precision trig difference flips a float rounding (then <= 1e-5)."""
+unless a last-place double-precision trig difference flips a float rounding (then <= 1e-5).
+The *_fp64 fixtures belong to the binary64 mode: exact for the oracle, 1e-9 relative per step
+(re-synchronised to the fixture after every step) for the HIP path."""
 import glob
 import os
 
@@ -19,6 +21,8 @@ EXACT = {"frozenlake", "frozenlake_8x8", "taxi", "cliffwalking", "pong", "breako
 def load(path):
     name = os.path.basename(path)[:-4]
     z = np.load(path, allow_pickle=False)
+    if name.endswith("_fp64"):
+        return name, z, None
     rows = str(z["map_rows"]).split("/") if "map_rows" in z.files else None
     return name, z, rows
 
@@ -32,20 +36,24 @@ def palette_index(frames):
 
 
 def test_fixtures_present():
-    assert len(FILES) == 12
+    assert len(FILES) == 17
 
 
 @pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f)[:-4] for f in FILES])
 def test_oracle_reproduces_golden(oracle, path):
     name, z, rows = load(path)
     n = z["actions"].shape[1]
-    v = oracle.OracleVec(getattr(oracle, ENV_OF[name]), n, seed=int(z["seed"]), map_rows=rows)
+    fp64 = name.endswith("_fp64")
+    v = oracle.OracleVec(getattr(oracle, ENV_OF[name[:-5] if fp64 else name]), n, seed=int(z["seed"]), map_rows=rows,
+                         flags=oracle.FP64 if fp64 else 0)
     v.reset()
     assert np.array_equal(v.get_state_raw(), z["init"])
     frames = []
     for t in range(z["actions"].shape[0]):
         r, d, _ = v.step(z["actions"][t])
         assert np.array_equal(r, z["rewards"][t]) and np.array_equal(d, z["dones"][t])
+        if fp64:
+            assert np.array_equal(v.get_state_raw(), z["states"][t])
         if name in INDEXED and t % 150 == 149:
             frames.append(palette_index(v.get_obs()[:8]))
     assert np.array_equal(v.get_state_raw(), z["final"])
@@ -61,6 +69,8 @@ def test_gpu_reproduces_golden(path):
 
     name, z, rows = load(path)
     n = z["actions"].shape[1]
+    if name.endswith("_fp64"):
+        return gpu_fp64_golden(name, z, n)
     g = DeviceBatch(ctx(), getattr(L, "ENV_" + ENV_OF[name]), n, seed=int(z["seed"]), map_rows=rows)
     g.reset()
     assert np.array_equal(g.get_state_raw(), z["init"])  # Reset() draws are integer / one-rounding work: exact
@@ -93,3 +103,25 @@ def test_gpu_reproduces_golden(path):
         assert same, "golden continuous-control trajectory not bit-identical (%d reward mismatches)" % mismatched
     if frames:
         assert np.array_equal(np.stack(frames), z["frame_index" if name in INDEXED else "frame_masks"])
+
+
+def gpu_fp64_golden(name, z, n):
+    from gpu_common import L, ctx
+    from gym_amd.engine import DeviceBatch
+
+    g = DeviceBatch(ctx(), getattr(L, "ENV_" + ENV_OF[name[:-5]]), n, seed=int(z["seed"]), mode=L.MODE_FP64)
+    g.reset()
+    a, ai = g.split_state(g.get_state_raw())
+    b, bi = g.split_state(z["init"].copy())
+    assert np.array_equal(ai, bi) and np.abs(a - b).max() <= 1e-15
+    prev = z["init"]
+    for t in range(z["actions"].shape[0]):
+        g.set_state_raw(prev)  # re-synchronise: every step starts from the fixture's state
+        _, r, d, _ = g.step_host(z["actions"][t])
+        a, ai = g.split_state(g.get_state_raw())
+        b, bi = g.split_state(z["states"][t].copy())
+        err = np.abs(a - b) / np.maximum(np.abs(b), 1e-6)
+        assert err.max() <= 1e-9, (t, err.max())
+        assert np.array_equal(ai, bi) and np.array_equal(d, z["dones"][t])
+        assert np.abs(r.astype(np.float64) - z["rewards"][t]).max() <= 1e-9 * max(1.0, np.abs(z["rewards"][t]).max())
+        prev = z["states"][t]

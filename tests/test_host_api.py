@@ -191,3 +191,23 @@ def test_vector_env_drop_in(oracle):
     big.Reset()
     obs, rew, done, _ = big.StepArrays(np.ones(5000, np.int32))
     assert (obs == 4).all() and not done.any()
+
+
+@pytest.mark.gpu
+def test_fp64_mode_through_the_host_mirror(oracle):
+    """the binary64 extension behind the same Env / VectorEnv surface: states come back as doubles"""
+    from gym_amd import _lib as L
+    env = G.Pendulum(seed=5, mode=L.MODE_FP64)
+    o = oracle.OracleVec(oracle.PENDULUM, 1, seed=5, flags=oracle.FP64)
+    s = env.Reset(); o.reset()
+    assert s.dtype == np.float64 and s.shape == (3,)
+    assert np.abs(s - o.get_obs()[:, 0]).max() <= 1e-15
+    s2, r, d, _ = env.Step(1.5)
+    orew, _, _ = o.step(np.array([1.5], np.float32))
+    assert abs(r - orew[0]) <= 1e-12 and not d and s2.dtype == np.float64
+    v = G.VectorEnv.Make(G.CartPole, 100, seed=9, mode=L.MODE_FP64)
+    st = v.Reset()
+    assert len(st) == 100 and all(isinstance(x, float) for x in st[0])
+    ov = oracle.OracleVec(oracle.CARTPOLE, 100, seed=9, flags=oracle.FP64)
+    ov.reset()
+    assert st[7] == tuple(ov.get_obs()[:, 7])  # the reset formula has no transcendental: exact
