@@ -1,4 +1,4 @@
-"""Parity at BASELINE.json's full sizes, through properties that do not need the oracle to step
+"""Parity at the headline benchmark sizes (16 Mi classic-control, 64 Mi tabular, 65 536 frame envs), through properties that do not need the oracle to step
 millions of envs: a K-step fused rollout equals K single steps; a batch split in two shards by
 global env index equals the unsplit batch; a window of the big batch equals an oracle batch keyed
 with the same global indices; statistics identities; frame invariants."""

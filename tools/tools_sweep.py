@@ -1,4 +1,4 @@
-"""Single-step kernel times of every env at its headline size (for DESIGN.md)."""
+"""Single-step kernel times of every env at its headline size."""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def run(args):
