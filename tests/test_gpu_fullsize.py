@@ -178,3 +178,38 @@ def test_acrobot_16mi_window_and_rk4_rollout(oracle):
     va, vb = torch_views(a), torch_views(b)
     assert torch.equal(va["state_real"].view(torch.int64), vb["state_real"].view(torch.int64))
     assert torch.equal(va["obs"].view(torch.int32), vb["obs"].view(torch.int32))
+
+
+@pytest.mark.parametrize("env_id", [L.ENV_MOUNTAINCAR, L.ENV_MOUNTAINCAR_CONT, L.ENV_PENDULUM])
+def test_mountaincar_pendulum_16mi(oracle, env_id):
+    """16 Mi envs, binary32 (EXACT) and binary64: a window against the oracle, then K fused steps == K single steps"""
+    import torch
+    k = 8
+    g, v = _window_matches_oracle(oracle, env_id, N16, base=N16 - 3001, width=3001, k=k, seed=6, flags=FUSED)
+    b = DeviceBatch(ctx(), env_id, N16, seed=6, flags=FUSED)
+    b.reset(); b.rollout(k); b.ctx.synchronize()
+    vb = torch_views(b)
+    assert torch.equal(v["state_real"].view(torch.int32), vb["state_real"].view(torch.int32))
+    assert torch.equal(v["state_int"], vb["state_int"])
+    assert g.stats().episodes == b.stats().episodes
+    g.close(); b.close()
+
+    # binary64 mode: the window within 1e-9 of the oracle's binary64 form after k free-running steps
+    base, width = 12345678, 2048
+    g = DeviceBatch(ctx(), env_id, N16, seed=6, flags=FUSED, mode=L.MODE_FP64)
+    o = oracle.OracleVec(env_id, width, seed=6, flags=oracle.AUTORESET | oracle.FP64, env_index_base=base)
+    g.reset(); o.reset()
+    for _ in range(k):
+        g.step_random(); o.step_random()
+    g.ctx.synchronize()
+    v = torch_views(g)
+    orr, oi = o.get_state()
+    gr = v["state_real"][:, base:base + width].cpu().numpy()
+    assert gr.dtype == np.float64
+    assert (np.abs(gr - orr) / np.maximum(np.abs(orr), 1e-6)).max() <= 1e-9
+    assert np.array_equal(v["state_int"][:, base:base + width].cpu().numpy(), oi)
+    b = DeviceBatch(ctx(), env_id, N16, seed=6, flags=FUSED, mode=L.MODE_FP64)
+    b.reset(); b.rollout(k); b.ctx.synchronize()
+    vb = torch_views(b)
+    assert torch.equal(v["state_real"].view(torch.int64), vb["state_real"].view(torch.int64))
+    assert torch.equal(v["state_int"], vb["state_int"])
