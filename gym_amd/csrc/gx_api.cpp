@@ -80,6 +80,17 @@ struct gx_vec {
   void* d_actions = nullptr;  // staging for the host path
   uint32_t* h_error = nullptr;  // pinned
   StatSlot* h_stat = nullptr;   // pinned
+  // Host path of small batches: pinned, device-mapped staging.  The step kernel reads the
+  // actions from it, a gather kernel writes the requested results into it, gx_vec_wait copies
+  // them to the caller's buffers.
+  char* h_stage = nullptr;  // host address
+  char* d_stage = nullptr;  // the same memory as the device addresses it
+  size_t stage_reward = 0, stage_done = 0, stage_trunc = 0, stage_obs = 0, stage_obs_pitch = 0;  // actions sit at offset 0
+  bool stage_pending = false;  // a staged step whose results gx_vec_wait still has to hand over
+  void* pend_obs = nullptr;
+  void* pend_reward = nullptr;
+  uint8_t* pend_done = nullptr;
+  uint8_t* pend_trunc = nullptr;
   bool frames_valid = false;
   // set by set_state: the state may violate the invariants the BOUNDED kernels rely on
   // until one step with auto-reset has run
@@ -506,6 +517,7 @@ extern "C" int gx_vec_destroy(gx_vec* v) {
   for (void* p : dev)
     if (p) (void)hipFree(p);
   if (v->h_error) (void)hipHostFree(v->h_error);
+  if (v->h_stage) (void)hipHostFree(v->h_stage);
   if (v->h_stat) (void)hipHostFree(v->h_stat);
   delete v;
   return GX_OK;
@@ -583,6 +595,25 @@ extern "C" int gx_vec_create(gx_ctx* ctx, const gx_desc* desc, gx_vec** out) {
   if (v->d_trunc) VEC_TRY(hipMemset(v->d_trunc, 0, v->stride));
   VEC_TRY(hipMemset(v->d_actions, 0, v->stride * 4));
   if (v->is_acrobot64) VEC_TRY(hipMalloc((void**)&v->d_obs, (size_t)6 * v->stride * 4));
+  if (!v->is_frame) {
+    // staging for the host path while a step's traffic is small enough that latency, not PCIe
+    // bandwidth, sets its cost
+    size_t limit = kStageLimitBytes;
+    if (const char* s = std::getenv("GYMX_STAGE_LIMIT")) limit = (size_t)std::atoll(s);  // tuning aid; 0 disables
+    auto up16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
+    const size_t esz = dtype_size(in.obs_dtype);
+    v->stage_reward = up16(v->stride * 4);
+    v->stage_done = v->stage_reward + up16(v->n * dtype_size(in.reward_dtype));
+    v->stage_trunc = v->stage_done + up16(v->n);
+    v->stage_obs = v->stage_trunc + up16(v->n);
+    v->stage_obs_pitch = up16(v->n * esz);
+    const size_t total = v->stage_obs + (size_t)in.obs_dim * v->stage_obs_pitch;
+    if (total <= limit) {
+      VEC_TRY(hipHostMalloc((void**)&v->h_stage, total, hipHostMallocMapped));
+      VEC_TRY(hipHostGetDevicePointer((void**)&v->d_stage, v->h_stage, 0));
+      std::memset(v->h_stage, 0, total);
+    }
+  }
   if (v->is_frame) VEC_TRY(hipMalloc((void**)&v->d_frames, v->n * (size_t)in.obs_dim));
 
   // launch geometry: workgroups grid-stride over lanes of `envs_per_lane` envs, two trips
@@ -735,6 +766,30 @@ extern "C" int gx_vec_set_state(gx_vec* v, const void* host, size_t bytes) {
   return GX_OK;
 }
 
+// The observation rows as the device holds them: (first row, bytes between rows).
+static const char* obs_rows(const gx_vec* v, size_t* pitch) {
+  const size_t esz = dtype_size(v->info.obs_dtype);
+  *pitch = v->stride * esz;
+  if (v->is_tabular) return reinterpret_cast<const char*>(v->d_int);
+  return v->is_acrobot64 ? reinterpret_cast<const char*>(v->d_obs) : static_cast<const char*>(v->d_real);
+}
+
+// Staged host path: hands the results of the pending step to the caller's buffers.
+static int finish_staged(gx_vec* v) {
+  HIP_TRY(hipStreamSynchronize(v->ctx->compute));
+  const gx_info& in = v->info;
+  if (v->pend_reward) std::memcpy(v->pend_reward, v->h_stage + v->stage_reward, v->n * dtype_size(in.reward_dtype));
+  if (v->pend_done) std::memcpy(v->pend_done, v->h_stage + v->stage_done, v->n);
+  if (v->pend_trunc) std::memcpy(v->pend_trunc, v->h_stage + v->stage_trunc, v->n);
+  if (v->pend_obs) {
+    const size_t row = v->n * dtype_size(in.obs_dtype);
+    for (int c = 0; c < in.obs_dim; c++)
+      std::memcpy(static_cast<char*>(v->pend_obs) + (size_t)c * row, v->h_stage + v->stage_obs + (size_t)c * v->stage_obs_pitch, row);
+  }
+  v->stage_pending = false;
+  return GX_OK;
+}
+
 // enqueue the device->host copy of the observation on `stream`
 static int copy_obs(gx_vec* v, void* host, hipStream_t stream) {
   const gx_info& in = v->info;
@@ -778,6 +833,33 @@ extern "C" int gx_vec_step_async(gx_vec* v, const void* h_actions, void* h_obs, 
       for (uint64_t i = 0; i < v->n; i++)
         if ((uint32_t)act[i] > 2u) return fail(GX_ERR_INVALID, "Acrobot: action %d of env %llu is outside {0,1,2}", act[i], (unsigned long long)i);
   }
+  if (v->h_stage) {
+    if (v->stage_pending) {  // a step that was never waited for: its results go to its buffers first
+      int rc = finish_staged(v);
+      if (rc) return rc;
+    }
+    std::memcpy(v->h_stage, h_actions, v->n * 4);
+    int rc = launch_step(v, v->d_stage, 1, v->stride, GX_POLICY_DEVICE_ACTIONS, c->compute);
+    if (rc) return rc;
+    GatherArgs g{};
+    auto add = [&g](const void* src, size_t offset, size_t bytes, char* base) { g.seg[g.count++] = GatherSegment{src, base + offset, bytes}; };
+    if (h_reward) add(v->d_reward, v->stage_reward, v->n * dtype_size(v->info.reward_dtype), v->d_stage);
+    if (h_done) add(v->d_done, v->stage_done, v->n, v->d_stage);
+    if (h_truncated) add(v->d_trunc, v->stage_trunc, v->n, v->d_stage);
+    if (h_obs) {
+      size_t pitch = 0;
+      const char* rows = obs_rows(v, &pitch);
+      for (int c = 0; c < v->info.obs_dim; c++)
+        add(rows + (size_t)c * pitch, v->stage_obs + (size_t)c * v->stage_obs_pitch, v->n * dtype_size(v->info.obs_dtype), v->d_stage);
+    }
+    if (g.count) {
+      const uint64_t blocks = (v->n * 8 / 16 + kBlock - 1) / kBlock;  // the widest row: 8 bytes per env
+      HIP_TRY(launch_gather_segments(g, dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(blocks, 256))), c->compute));
+    }
+    v->pend_obs = h_obs; v->pend_reward = h_reward; v->pend_done = h_done; v->pend_trunc = h_truncated;
+    v->stage_pending = true;
+    return GX_OK;
+  }
   HIP_TRY(hipMemcpyAsync(v->d_actions, h_actions, v->n * 4, hipMemcpyHostToDevice, c->copy));
   HIP_TRY(hipEventRecord(c->ev_in, c->copy));
   HIP_TRY(hipStreamWaitEvent(c->compute, c->ev_in, 0));
@@ -803,6 +885,10 @@ extern "C" int gx_vec_wait(gx_vec* v) {
   if (!v) return fail(GX_ERR_INVALID, "gx_vec_wait: null batch");
   gx_ctx* c = v->ctx;
   HIP_TRY(hipSetDevice(c->device));
+  if (v->stage_pending) {
+    int rc = finish_staged(v);
+    if (rc) return rc;
+  }
   HIP_TRY(hipStreamSynchronize(c->compute));
   if (has_error_flag(v)) HIP_TRY(hipMemcpyAsync(v->h_error, v->d_error, 4, hipMemcpyDeviceToHost, c->copy));
   HIP_TRY(hipStreamSynchronize(c->copy));

@@ -20,6 +20,11 @@ constexpr int kClassicBlock = 64;
 // 0.343 / 0.360 ms, full Taxi-v3 (14 KB) 0.355 / 0.418 ms.
 constexpr int kTabularBlock = 256, kTabularBlockSmallTable = 128;
 constexpr size_t kSmallTableBytes = 2048;
+// The host path stages a step's actions and results in pinned mapped memory up to this many
+// bytes per step; beyond it the copies run on the copy engine (a separate stream).  CartPole,
+// actions in, reward + done + observation out, ms per step staged / copy engine: 1 024 envs
+// 0.023 / 0.056, 32 768 envs 0.053 / 0.075, 65 536 envs 0.087 / 0.094, 262 144 envs 0.339 / 0.185.
+constexpr size_t kStageLimitBytes = 2u << 20;
 constexpr int kEnvsPerThread = 4;    // one 16-byte vector per component per lane
 constexpr int kStatFields = 6;
 

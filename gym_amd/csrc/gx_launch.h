@@ -49,6 +49,19 @@ hipError_t launch_invaders_reset(const StepArgs& a, dim3 grid, hipStream_t strea
 hipError_t launch_invaders_raster(const StepArgs& a, uint8_t* frames, hipStream_t stream);
 hipError_t launch_invaders_sample(const StepArgs& a, void* out, dim3 grid, hipStream_t stream);
 
+// host path of small batches (gx_hostpath.hip)
+struct GatherSegment {
+  const void* src;  // device row
+  void* dst;        // device address of the pinned staging buffer
+  uint64_t bytes;
+};
+constexpr int kMaxGatherSegments = 12;
+struct GatherArgs {
+  GatherSegment seg[kMaxGatherSegments];
+  int count;
+};
+hipError_t launch_gather_segments(const GatherArgs& g, dim3 grid, hipStream_t stream);
+
 // statistics (gx_stats.hip)
 hipError_t launch_stats_reduce(const StatSlot* slots, int num_slots, StatSlot* out, hipStream_t stream);
 hipError_t launch_stats_init(StatSlot* slots, int num_slots, hipStream_t stream);

@@ -587,3 +587,39 @@ def test_fp64_mode_rollout_matches_single_steps(oracle):
         assert np.array_equal(bits(ar), bits(br)) and np.array_equal(ai, bi), env_id
         sa, sb = a.stats(), b.stats()
         assert sa.episodes == sb.episodes and sa.sum_return == sb.sum_return
+
+
+@pytest.mark.parametrize("stage_limit", ["0", None], ids=["copy-engine", "staged"])
+@pytest.mark.parametrize("env_id", [L.ENV_CARTPOLE, L.ENV_PENDULUM, L.ENV_FROZENLAKE])
+def test_host_path_both_transports(oracle, env_id, stage_limit, monkeypatch):
+    """gx_vec_step_async / gx_vec_wait through the pinned staging (small batches) and through the copy
+    engine (what large batches use), every output requested, a ragged batch size"""
+    if stage_limit is None:
+        monkeypatch.delenv("GYMX_STAGE_LIMIT", raising=False)
+    else:
+        monkeypatch.setenv("GYMX_STAGE_LIMIT", stage_limit)
+    n = 1003
+    g, o = make_pair(oracle, env_id, n, seed=41, flags=L.AUTORESET | L.RECORD_STATS, time_limit=7)
+    g.reset(); o.reset()
+    rng = np.random.default_rng(env_id)
+    for t in range(20):
+        a = random_actions(rng, env_id, n)
+        obs, rew, done, trunc = g.step_host(a, want_obs=True, want_trunc=True)
+        orew, odone, otrunc = o.step(a)
+        assert np.array_equal(rew.astype(np.float64), orew), t
+        assert np.array_equal(done, odone) and np.array_equal(trunc, otrunc), t
+        assert np.array_equal(bits(obs), bits(o.get_obs())), t
+    # two steps without a wait in between: the first one's results still reach its buffers
+    import ctypes as C
+    lib = L.load()
+    a1, a2 = random_actions(rng, env_id, n), random_actions(rng, env_id, n)
+    r1 = np.empty(n, g.reward_dtype); r2 = np.empty(n, g.reward_dtype)
+    d1 = np.empty(n, np.uint8); d2 = np.empty(n, np.uint8)
+    p = lambda x: x.ctypes.data_as(C.c_void_p)
+    L.check(lib.gx_vec_step_async(g._h, p(a1), None, p(r1), p(d1), None))
+    L.check(lib.gx_vec_step_async(g._h, p(a2), None, p(r2), p(d2), None))
+    L.check(lib.gx_vec_wait(g._h))
+    o1, od1, _ = o.step(a1)
+    o2, od2, _ = o.step(a2)
+    assert np.array_equal(r1.astype(np.float64), o1) and np.array_equal(d1, od1)
+    assert np.array_equal(r2.astype(np.float64), o2) and np.array_equal(d2, od2)
