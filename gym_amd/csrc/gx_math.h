@@ -52,6 +52,19 @@ GX_HD void quadrant(int q, double sn, double cs, double& s, double& c) {
 }
 
 // sin(x) and cos(x) in binary64 for |x| <= pi/4, no argument reduction.
+// a * b + k for a compile-time constant k.  Written as one v_fma_f64 with the constant in a scalar
+// register pair: left to itself the compiler puts such a constant into a vector register pair
+// (two moves) and accumulates into it, three vector instructions per polynomial term.
+GX_HD double fma_k(double a, double b, double k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k));
+  return r;
+#else
+  return fma(a, b, k);
+#endif
+}
+
 // Minimax kernels of the classic fdlibm form (sin: x + x^3 S(x^2), cos:
 // 1 - x^2/2 + x^4 C(x^2)) evaluated by Horner's rule with fused multiply-adds;
 // the error stays under one unit in the last place of the double, so rounding
@@ -64,17 +77,17 @@ GX_HD void sincos_small(double x, double& s, double& c) {
   const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
                C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
   const double z = x * x;
-  double rs = fma(z, S6, S5);
-  rs = fma(z, rs, S4);
-  rs = fma(z, rs, S3);
-  rs = fma(z, rs, S2);
-  rs = fma(z, rs, S1);
+  double rs = fma_k(z, S6, S5);
+  rs = fma_k(z, rs, S4);
+  rs = fma_k(z, rs, S3);
+  rs = fma_k(z, rs, S2);
+  rs = fma_k(z, rs, S1);
   s = fma(z * x, rs, x);
-  double rc = fma(z, C6, C5);
-  rc = fma(z, rc, C4);
-  rc = fma(z, rc, C3);
-  rc = fma(z, rc, C2);
-  rc = fma(z, rc, C1);
+  double rc = fma_k(z, C6, C5);
+  rc = fma_k(z, rc, C4);
+  rc = fma_k(z, rc, C3);
+  rc = fma_k(z, rc, C2);
+  rc = fma_k(z, rc, C1);
   // 1 - (z/2 - z*z*rc), the subtraction of the small tail rounded once
   const double hz = 0.5 * z;
   c = 1.0 - fma(-(z * z), rc, hz);
@@ -100,18 +113,18 @@ GX_HD void sincos_bounded(double x, double& s, double& c) {
   double t = fma(-fn, P2, r0 - r);             // what the rounding of r dropped
   t = fma(-fn, P3, t);                         // tail
   const double z = r * r;
-  double rs = fma(z, S6, S5);
-  rs = fma(z, rs, S4);
-  rs = fma(z, rs, S3);
-  rs = fma(z, rs, S2);
+  double rs = fma_k(z, S6, S5);
+  rs = fma_k(z, rs, S4);
+  rs = fma_k(z, rs, S3);
+  rs = fma_k(z, rs, S2);
   const double v = z * r;
   // r - ((z (t/2 - v rs) - t) - v S1)
   const double sn = r - (fma(z, fma(0.5, t, -(v * rs)), -t) - v * S1);
-  double rc = fma(z, C6, C5);
-  rc = fma(z, rc, C4);
-  rc = fma(z, rc, C3);
-  rc = fma(z, rc, C2);
-  rc = fma(z, rc, C1);
+  double rc = fma_k(z, C6, C5);
+  rc = fma_k(z, rc, C4);
+  rc = fma_k(z, rc, C3);
+  rc = fma_k(z, rc, C2);
+  rc = fma_k(z, rc, C1);
   const double hz = 0.5 * z;
   const double w = 1.0 - hz;
   const double cs = w + (((1.0 - w) - hz) + fma(z * z, rc, -(r * t)));
