@@ -220,7 +220,7 @@ struct Pendulum64 {
   static __device__ __forceinline__ void step(double (&s)[NS], int32_t& steps, Act action, Rew& reward, bool& done) {
     const double max_speed = 8.0, max_torque = 2.0, dt = 0.05, g = 10.0, m = 1.0, l = 1.0;
 
-    const double theta = ::atan2(s[1], s[0]);
+    const double theta = math::atan2_f64(s[1], s[0]);
     const double thetaDot = s[2];
     const double u = clampd((double)action, -max_torque, max_torque);
 
@@ -280,8 +280,8 @@ struct AcrobotEuler64 {
     const double MAX_VEL_1 = 4 * M_PI, MAX_VEL_2 = 9 * M_PI;
     const double dt = 0.2, g = 9.8;
 
-    double theta1 = ::atan2(s[1], s[0]);
-    double theta2 = ::atan2(s[3], s[2]);
+    double theta1 = math::atan2_f64(s[1], s[0]);
+    double theta2 = math::atan2_f64(s[3], s[2]);
     double dtheta1 = s[4];
     double dtheta2 = s[5];
     const double u = action == 0 ? -1.0 : (action == 2 ? 1.0 : 0.0);

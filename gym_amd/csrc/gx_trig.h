@@ -42,7 +42,7 @@ struct Trig<GX_MODE_EXACT, false> {
   static __device__ __forceinline__ float cos_minus_half_pi(float x) { return (float)::cos((double)x - M_PI / 2.0); }
   // (float)Math.Sin(x + Math.PI)
   static __device__ __forceinline__ float sin_plus_pi(float x) { return (float)::sin((double)x + M_PI); }
-  static __device__ __forceinline__ float atan2(float y, float x) { return (float)::atan2((double)y, (double)x); }
+  static __device__ __forceinline__ float atan2(float y, float x) { return (float)math::atan2_f64((double)y, (double)x); }
 };
 
 template <>
@@ -76,7 +76,7 @@ struct Trig<GX_MODE_EXACT, true> {
     math::sincos_bounded((double)x + M_PI, sd, cd);
     return (float)sd;
   }
-  static __device__ __forceinline__ float atan2(float y, float x) { return (float)::atan2((double)y, (double)x); }
+  static __device__ __forceinline__ float atan2(float y, float x) { return (float)math::atan2_f64((double)y, (double)x); }
 };
 
 template <>

@@ -4,6 +4,7 @@
 //   sincos_small: (float)sin / (float)cos of every `stride`-th float in
 //                 [-pi/4, pi/4] against (float)sin((double)x), (float)cos(...)
 //   sincos_bounded: floats in [-16, 16] and their shifts by -pi/2 and +pi, the same way
+//   atan2_f64: random float pairs against (float)atan2((double)y, (double)x), and in binary64
 //   div_by_total_mass: every `stride`-th float in [2^-100, 2^100], both signs,
 //                 against x / 1.1f
 // Prints the mismatch counts; exit status 0 when both are within bounds.
@@ -89,6 +90,37 @@ int main(int argc, char** argv) {
       for (float x : ax) worst_at = std::fmax(worst_at, std::fabs((double)gx::math::atan2f_fast(y, x) - std::atan2((double)y, (double)x)));
   }
   std::printf("sincosf_bounded: worst absolute error %.3g; atan2f_fast: %.3g\n", worst_f, worst_at);
+  // ---- atan2_f64: rounded to float against (float)atan2 for float arguments (unit-circle pairs, the
+  // small reset values, wide states), the error in binary64 units in the last place, special values
+  unsigned long long na = 0, bad_a = 0;
+  double worst_ulp = 0.0;
+  {
+    uint64_t state = 0xD1B54A32D192ED03ull;
+    auto next = [&]() { state ^= state << 13; state ^= state >> 7; state ^= state << 17; return (double)(state >> 11) * 0x1.0p-53; };
+    const long long count = 40000000ll / (stride > 64 ? 8 : 1);
+    for (long long i = 0; i < count; i++) {
+      const float scale = (i % 3) == 0 ? 1.0f : ((i % 3) == 1 ? 0.05f : 40.0f);
+      const float y = (float)(next() * 2 - 1) * scale, x = (float)(next() * 2 - 1) * scale;
+      const double got = gx::math::atan2_f64((double)y, (double)x), ref = std::atan2((double)y, (double)x);
+      na++;
+      bad_a += to_bits((float)got) != to_bits((float)ref);
+      const double ulp = std::ldexp(1.0, std::ilogb(std::fabs(ref) > 0 ? ref : 1.0) - 52);
+      if (ref != 0.0) worst_ulp = std::fmax(worst_ulp, std::fabs(got - ref) / ulp);
+    }
+  }
+  bool special_ok = true;
+  {
+    const double inf = INFINITY, vals[] = {0.0, -0.0, 1.0, -1.0, 3.5, -2.25, 1e-300, -1e-300, 1e300, inf, -inf};
+    for (double y : vals)
+      for (double x : vals) {
+        const double got = gx::math::atan2_f64(y, x), ref = std::atan2(y, x);
+        const bool same = std::fabs(got - ref) <= 2.3e-16 * std::fabs(ref) && std::signbit(got) == std::signbit(ref);
+        if (!same) { special_ok = false; std::printf("atan2_f64(%g, %g) = %.17g, libm %.17g\n", y, x, got, ref); }
+      }
+    special_ok = special_ok && std::isnan(gx::math::atan2_f64(NAN, 1.0)) && std::isnan(gx::math::atan2_f64(1.0, NAN));
+  }
+  std::printf("atan2_f64: %llu float pairs, mismatches after rounding to float %llu, worst error %.3f ulp, special values %s\n", na, bad_a,
+              worst_ulp, special_ok ? "ok" : "WRONG");
   // ---- division by 1.1f
   const float c11 = 1.0f + 0.1f;
   unsigned long long nd = 0, bad_d = 0;
@@ -103,6 +135,6 @@ int main(int argc, char** argv) {
     }
   std::printf("div_by_total_mass: %llu inputs, mismatches %llu\n", nd, bad_d);
   // one rounding-boundary event per ~2^28 trig calls is expected; the division must be exact
-  const bool ok = worst < 1e-15 && worst_f < 3e-7 && worst_at < 6e-7 && bad_d == 0 && bad_b * (1ull << 24) <= nb + (1ull << 24) && bad_s * (1ull << 24) <= n + (1ull << 24) && bad_c * (1ull << 24) <= n + (1ull << 24);
+  const bool ok = special_ok && worst_ulp <= 2.0 && bad_a * (1ull << 23) <= na + (1ull << 23) && worst < 1e-15 && worst_f < 3e-7 && worst_at < 6e-7 && bad_d == 0 && bad_b * (1ull << 24) <= nb + (1ull << 24) && bad_s * (1ull << 24) <= n + (1ull << 24) && bad_c * (1ull << 24) <= n + (1ull << 24);
   return ok ? 0 : 1;
 }
