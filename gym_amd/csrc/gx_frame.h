@@ -1,4 +1,4 @@
-// Shared pieces of the 210x160x3 frame rasterisers (Pong, Breakout).
+// Shared pieces of the 210x160x3 frame rasterisers (Pong, Breakout, SpaceInvaders).
 //
 // A frame row is 160 pixels = 40 groups of four pixels; a lane produces one
 // group = 12 bytes and writes it with one store, so a wave writes 768
