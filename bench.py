@@ -188,7 +188,10 @@ def main():
         if args.share_device:
             local_rank %= torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group(args.dist_backend, rank=rank, world_size=world)
+        # naming the device binds the RCCL communicator to this rank's GPU up front (no guessing at
+        # the first barrier)
+        kw = {"device_id": torch.device("cuda", local_rank)} if args.dist_backend == "nccl" else {}
+        dist_mod.init_process_group(args.dist_backend, rank=rank, world_size=world, **kw)
         dist = dist_mod
         global COLLECTIVE_DEVICE
         COLLECTIVE_DEVICE = "cuda" if args.dist_backend == "nccl" else "cpu"
@@ -303,8 +306,11 @@ def main():
                             "mean_return": ep["sum_return"] / max(ep["episodes"], 1),
                             "min_return": ep["min_return"], "max_return": ep["max_return"]}
 
-    if rank == 0 and world == 1 and not args.no_extra and args.env == "cartpole":
-        out["extra"] = extra_measurements(ctx, n, stream_ptr)
+    if not args.no_extra and args.env == "cartpole":
+        # every rank takes part: the timings are maxima over ranks, the rollout all-reduces its statistics
+        extra = extra_measurements(ctx, n, stream_ptr, dist, rank, world)
+        if rank == 0:
+            out["extra"] = extra
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.env)
         allc = cpu_baseline_all_cores(args.env)
@@ -317,23 +323,39 @@ def main():
         dist.destroy_process_group()
 
 
-def extra_measurements(ctx, n, stream_ptr):
+def extra_measurements(ctx, n, stream_ptr, dist, rank, world):
     """Secondary numbers named by the headline metric: Acrobot single-step (reference dynamics)
-    and the fused 64-step RK4/binary64 rollout (FP64 vector-ALU bound)."""
-    res = {"hbm_copy_ceiling_GBps_measured": d2d_copy_rate()}
+    and the fused 64-step RK4/binary64 rollout (FP64 vector-ALU bound), n envs per rank.  Rates are
+    whole-job (all ranks' env-steps over the slowest rank's wall time between barriers); the
+    kernel times are rank 0's, from HIP events."""
+    res = {}
+    if world == 1:
+        res["hbm_copy_ceiling_GBps_measured"] = d2d_copy_rate()
     flags = L.AUTORESET | L.RECORD_STATS
-    b = DeviceBatch(ctx, L.ENV_ACROBOT, n, seed=1, flags=flags)
+    base = rank * n
+    b = DeviceBatch(ctx, L.ENV_ACROBOT, n, seed=1, flags=flags, env_index_base=base)
     b.reset()
-    _, ms = time_steps(b, lambda: b.step_random(stream_ptr), 20, 3, None)
-    res["acrobot_euler_exact_single_step"] = {"env_steps_per_s": n / (ms * 1e-3), "kernel_ms": ms,
-                                             "hbm_GBps": (B_ALG["acrobot"] - 4) * n / (ms * 1e-3) / 1e9}
+    steps = 20
+    wall, ms = time_steps(b, lambda: b.step_random(stream_ptr), steps, 3, dist)
+    res["acrobot_euler_exact_single_step"] = {"env_steps_per_s": n * world * steps / wall, "n_gpus": world, "kernel_ms": ms,
+                                             "hbm_GBps_per_gpu": (B_ALG["acrobot"] - 4) * n / (ms * 1e-3) / 1e9}
     b.close()
     k = 64
-    b = DeviceBatch(ctx, L.ENV_ACROBOT, n, seed=1, flags=flags | L.ACROBOT_RK4)
+    b = DeviceBatch(ctx, L.ENV_ACROBOT, n, seed=1, flags=flags | L.ACROBOT_RK4, env_index_base=base)
     b.reset()
-    _, ms = time_steps(b, lambda: b.rollout(k, L.POLICY_RANDOM, None, stream_ptr), 3, 1, None)
-    rate = n * k / (ms * 1e-3)
-    res["acrobot_rk4_fp64_rollout64"] = {"env_steps_per_s": rate, "kernel_ms": ms,
+
+    def rollout():
+        # one fused rollout, then the episode statistics reduced on the device and across ranks
+        b.rollout(k, L.POLICY_RANDOM, None, stream_ptr)
+        if dist is not None:
+            torch.cuda.current_stream().synchronize()
+            allreduce_stats(b.stats(), dist, device=COLLECTIVE_DEVICE)
+
+    steps = 3
+    wall, ms = time_steps(b, rollout, steps, 1, dist)
+    rate = n * k / (ms * 1e-3)  # per GPU, from the kernel time
+    res["acrobot_rk4_fp64_rollout64"] = {"env_steps_per_s": n * world * k * steps / wall, "n_gpus": world,
+                                         "env_steps_per_s_per_gpu_kernel": rate, "kernel_ms": ms,
                                          "fp64_TFLOPs": rate * ACROBOT_RK4_FLOPS_COUNTED / 1e12,
                                          "frac_of_fp64_valu_peak": rate * ACROBOT_RK4_FLOPS_COUNTED / 1e12 / FP64_VALU_PEAK_TFLOPS,
                                          "fp64_TFLOPs_arith_only": rate * ACROBOT_RK4_FLOPS / 1e12}
