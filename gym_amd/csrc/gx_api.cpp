@@ -633,6 +633,9 @@ extern "C" int gx_vec_create(gx_ctx* ctx, const gx_desc* desc, gx_vec** out) {
     }
     uint64_t blocks = (groups + v->block - 1) / v->block;
     uint64_t cap = std::max<uint64_t>((blocks + 1) / 2, (uint64_t)ctx->num_cus * 4);
+    // a large table is staged in LDS once per workgroup: four trips amortise that better
+    // (Taxi at 64 Mi envs: 0.322 -> 0.311 ms, full Taxi-v3 0.364 -> 0.358 ms)
+    if (v->is_tabular && table.size() * 4 > kSmallTableBytes) cap = std::max<uint64_t>((blocks + 3) / 4, (uint64_t)ctx->num_cus * 4);
     if (const char* s = std::getenv("GYMX_GRID_BLOCKS")) {
       long long b = std::atoll(s);
       if (b > 0) cap = (uint64_t)b;
