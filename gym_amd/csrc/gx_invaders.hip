@@ -250,103 +250,155 @@ __device__ __forceinline__ uint32_t palette(uint32_t idx) {
          idx == kRed ? 0x0000FFu : idx == kWhite ? 0xFFFFFFu : 0u;
 }
 
-// One pixel of the palette image (eight 4-bit pixels per word) with the reference's
-// DrawRectangle bounds check (Envs.SpaceInvaders.cs:461-478).  Clear-then-set with two LDS
-// atomics: lanes painting other pixels of the same word do not interfere, and lanes painting
-// the same pixel within a layer write the same colour, so the last clear is always followed
-// by a set of that colour.
-__device__ __forceinline__ void put(uint32_t* img, int px, int py, uint32_t c) {
-  if (px >= 0 && px < kScreenW && py >= 0 && py < kScreenH) {
-    const int idx = py * kScreenW + px, sh = (idx & 7) * 4;
-    atomicAnd(&img[idx >> 3], ~(0xFu << sh));
-    atomicOr(&img[idx >> 3], c << sh);
-  }
-}
-
-// One workgroup per env.  Layers are painted in the source's order with a barrier between
-// layers of different colour; within a layer every pixel receives one colour.
+// One workgroup per env, one four-pixel group per lane and iteration; nothing is staged: a
+// lane decides the colour of its four pixels from the game state.  The layers are applied in the
+// source's drawing order (Envs.SpaceInvaders.cs:355-411: aliens, cannon, player bullets, alien
+// bullets, score, lives, ground line), a later layer overwriting an earlier one, which is what
+// painting into a frame does; a pixel off the screen is never visited, which is the reference's
+// DrawRectangle bounds check (:461-478).
 __global__ void __launch_bounds__(kBlock) invaders_raster_kernel(StepArgs a, uint8_t* __restrict__ frames) {
-  constexpr int kImgWords = kScreenW * kScreenH / 8;
-  __shared__ uint32_t img[kImgWords];
+  __shared__ uint32_t digit_rows[5][5];  // rows 10..14 of the frame as 160-bit masks (the score)
+  __shared__ int32_t alien_x[si::kCols], alien_y[si::kRows];
+  __shared__ uint8_t row_layers[kScreenH];  // which layers can touch a frame row (most rows: none)
   const uint64_t env = blockIdx.x;
   const int tid = threadIdx.x;
   const double* r = static_cast<const double*>(a.state_real);
   const int32_t* n = a.state_int;
-  for (int w = tid; w < kImgWords; w += kBlock) img[w] = 0;
+  const double formX = r[a.stride + env], formY = r[2 * a.stride + env];
+  // column / row origins exactly as the source computes them, (int)(formation + 12 col) and
+  // (int)(formation + 10 row): the cast truncates toward zero, so consecutive origins are 12 (10)
+  // apart give or take one
+  if (tid < si::kCols) alien_x[tid] = (int)(formX + tid * 12);
+  if (tid < si::kRows) alien_y[tid] = (int)(formY + tid * 10);
+  if (tid >= 32 && tid < 57) digit_rows[(tid - 32) / 5][(tid - 32) % 5] = 0;
   __syncthreads();
+  // score, :403, 480-525: character i at x = 10 + 6 i, rows 10..14
+  if (tid < 5) score_row_mask(digit_rows[tid], n[env], tid, 10, 6, false);
 
-  // aliens: 55 x 36 sprite cells, Envs.SpaceInvaders.cs:361-385, 413-435
-  {
-    const double formX = r[a.stride + env], formY = r[2 * a.stride + env];
-    const uint64_t aliens = (uint64_t)(uint32_t)n[6 * a.stride + env] | ((uint64_t)(uint32_t)n[7 * a.stride + env] << 32);
-    // sprite rows, bit dx = column dx: .X..X. / ..XX.. / .XXXX. / XX..XX / XXXXXX / .X..X.
-    const uint32_t sprite = 0x12u | (0x0Cu << 6) | (0x1Eu << 12) | (0x33u << 18) | (0x3Fu << 24);
-    const uint32_t last_row = 0x12u;
-    for (int c = tid; c < si::kRows * si::kCols * 36; c += kBlock) {
-      const int cell = c / 36, p = c - cell * 36, dy = p / 6, dx = p - dy * 6;
-      const int row = cell / si::kCols, col = cell - row * si::kCols;
-      const uint32_t bits = dy < 5 ? (sprite >> (6 * dy)) & 0x3Fu : last_row;
-      if (((aliens >> cell) & 1ull) && ((bits >> dx) & 1u)) {
-        const int x = (int)(formX + col * 12), y = (int)(formY + row * 10);  // (int) truncates toward zero
-        put(img, x + dx, y + dy, (uint32_t)(kMagenta + row));  // magenta, cyan, yellow, green, red
-      }
-    }
-  }
-  __syncthreads();
-  // player cannon, :388, 437-459: rows ...XX... / ..XXXX.. / ..XXXX.. / .XXXXXX. / XXXXXXXX x2
+  const uint64_t aliens = (uint64_t)(uint32_t)n[6 * a.stride + env] | ((uint64_t)(uint32_t)n[7 * a.stride + env] << 32);
+  const int x0 = alien_x[0], y0 = alien_y[0], y_end = alien_y[si::kRows - 1] + 6;
+  const int player_x = (int)r[env];
+  const int lives = n[a.stride + env];
+  const int shown = lives < 0 ? 0 : (lives > 13 ? 13 : lives);  // cannon 13 would start at x = -10
+  int npb = n[4 * a.stride + env], nab = n[5 * a.stride + env];
+  npb = npb > si::kMaxPB ? si::kMaxPB : npb;
+  nab = nab > si::kMaxAB ? si::kMaxAB : nab;
+  int pbx[si::kMaxPB], pby[si::kMaxPB], abx[si::kMaxAB], aby[si::kMaxAB];
+#pragma unroll
+  for (int b = 0; b < si::kMaxPB; b++) { pbx[b] = (int)r[(3 + 2 * b) * a.stride + env]; pby[b] = (int)r[(4 + 2 * b) * a.stride + env]; }
+#pragma unroll
+  for (int b = 0; b < si::kMaxAB; b++) { abx[b] = (int)r[(9 + 2 * b) * a.stride + env]; aby[b] = (int)r[(10 + 2 * b) * a.stride + env]; }
+  // alien sprite rows, bit dx = column dx: .X..X. / ..XX.. / .XXXX. / XX..XX / XXXXXX / .X..X. (:413-435)
+  const uint64_t sprite = 0x12ull | (0x0Cull << 6) | (0x1Eull << 12) | (0x33ull << 18) | (0x3Full << 24) | (0x12ull << 30);
+  // cannon rows ...XX... / ..XXXX.. / ..XXXX.. / .XXXXXX. / XXXXXXXX x2 (:437-459)
   const uint64_t cannon = 0x18ull | (0x3Cull << 8) | (0x3Cull << 16) | (0x7Eull << 24) | (0xFFull << 32) | (0xFFull << 40);
-  if (tid < 48) {
-    const int dy = tid >> 3, dx = tid & 7;
-    if ((cannon >> (8 * dy + dx)) & 1ull) put(img, (int)r[env] + dx, kScreenH - 40 + dy, kGreen);
+
+  enum : uint32_t { kLayerAliens = 1, kLayerCannon = 2, kLayerPlayerBullets = 4, kLayerAlienBullets = 8, kLayerHud = 16, kLayerGround = 32 };
+  if (tid < kScreenH) {
+    const int y = tid;
+    uint32_t f = 0;
+    if (y >= y0 - 1 && y < y_end + 1) f |= kLayerAliens;
+    if ((unsigned)(y - (kScreenH - 40)) < 6u) f |= kLayerCannon;
+#pragma unroll
+    for (int b = 0; b < si::kMaxPB; b++)
+      if (b < npb && (unsigned)(y - pby[b]) < 4u) f |= kLayerPlayerBullets;
+#pragma unroll
+    for (int b = 0; b < si::kMaxAB; b++)
+      if (b < nab && (unsigned)(y - aby[b]) < 4u) f |= kLayerAlienBullets;
+    if ((unsigned)(y - 10) < 6u) f |= kLayerHud;
+    if ((unsigned)(y - (kScreenH - 20)) < 2u) f |= kLayerGround;
+    row_layers[y] = (uint8_t)f;
   }
-  __syncthreads();
-  // player bullets (yellow) then alien bullets (red), :391-400
-  {
-    const int npb = n[4 * a.stride + env], nab = n[5 * a.stride + env];
-    if (tid < 8 * si::kMaxPB) {
-      const int b = tid >> 3, p = tid & 7;
-      if (b < npb) put(img, (int)r[(3 + 2 * b) * a.stride + env] + (p & 1), (int)r[(4 + 2 * b) * a.stride + env] + (p >> 1), kYellow);
-    }
-    __syncthreads();
-    if (tid < 8 * si::kMaxAB) {
-      const int b = tid >> 3, p = tid & 7;
-      if (b < nab) put(img, (int)r[(9 + 2 * b) * a.stride + env] + (p & 1), (int)r[(10 + 2 * b) * a.stride + env] + (p >> 1), kRed);
-    }
-  }
-  __syncthreads();
-  // score (white), :403, 480-525: character i at x = 10 + 6 i, rows 10..14
-  {
-    __shared__ uint32_t digit_rows[5][5];
-    if (tid < 25) digit_rows[tid / 5][tid % 5] = 0;
-    __syncthreads();
-    if (tid < 5) score_row_mask(digit_rows[tid], n[env], tid, 10, 6, false);
-    __syncthreads();
-    for (int c = tid; c < 5 * kScreenW; c += kBlock) {
-      const int dy = c / kScreenW, x = c - dy * kScreenW;
-      if ((digit_rows[dy][x >> 5] >> (x & 31)) & 1u) put(img, x, 10 + dy, kWhite);
-    }
-  }
-  __syncthreads();
-  // lives (green cannons), :404, 489-495: cannon i at (120 - 10 i, 10); only those that can
-  // touch the screen are visited
-  {
-    const int lives = n[a.stride + env];
-    const int shown = lives < 0 ? 0 : (lives > 13 ? 13 : lives);  // x + 7 < 0 from i = 13 on
-    for (int c = tid; c < shown * 48; c += kBlock) {
-      const int i = c / 48, p = c - i * 48, dy = p >> 3, dx = p & 7;
-      if ((cannon >> (8 * dy + dx)) & 1ull) put(img, (kScreenW - 40) - i * 10 + dx, 10 + dy, kGreen);
-    }
-  }
-  __syncthreads();
-  // ground line, :407-410
-  for (int c = tid; c < 2 * kScreenW / 8; c += kBlock) img[(kScreenH - 20) * kScreenW / 8 + c] = 0x11111111u * kGreen;
   __syncthreads();
 
   uint8_t* frame = frames + env * (uint64_t)kFrameBytes;
-  for (int c = tid; c < kGroupsPerFrame; c += kBlock) {
-    const uint32_t w = img[c >> 1] >> ((c & 1) * 16);
-    *reinterpret_cast<U3*>(frame + (uint64_t)c * 12) =
-        pack_rgb4(palette(w & 0xFu), palette((w >> 4) & 0xFu), palette((w >> 8) & 0xFu), palette((w >> 12) & 0xFu));
+  // group c = y * 40 + g; a workgroup step of 256 groups is six rows and sixteen groups
+  int y = tid / kGroupsPerRow, g = tid - y * kGroupsPerRow;
+  for (int c = tid; c < kGroupsPerFrame; c += kBlock, y += 6, g += 16) {
+    if (g >= kGroupsPerRow) { g -= kGroupsPerRow; y += 1; }
+    const uint32_t layers = row_layers[y];
+    if (layers == 0u) {
+      *reinterpret_cast<U3*>(frame + (uint64_t)c * 12) = U3{0u, 0u, 0u};
+      continue;
+    }
+    const int xg = 4 * g;
+    uint32_t idx[4] = {kBlack, kBlack, kBlack, kBlack};
+    // aliens, :361-385.  Row origins are 9..11 apart and a sprite is 6 tall, so the row whose
+    // sprite can cover y is floor((y - y0 + 1) / 10); the same with 12 and 6 for columns.
+    if (layers & kLayerAliens) {
+      int row = ((y - y0 + 1) * 205) >> 11;  // / 10, exact below 1024
+      row = row > si::kRows - 1 ? si::kRows - 1 : (row < 0 ? 0 : row);
+      const int dy = y - alien_y[row];
+      if ((unsigned)dy < 6u) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int d = xg + i - x0 + 1;
+          if (d >= 0) {
+            const int col = (d * 171) >> 11;  // / 12, exact below 512 (d <= 161 + |x0|; larger columns do not exist)
+            if (d < 512 && col < si::kCols) {
+              const int dx = xg + i - alien_x[col];
+              const int cell = row * si::kCols + col;
+              if ((unsigned)dx < 6u && ((aliens >> cell) & 1ull) && ((sprite >> (6 * dy + dx)) & 1ull))
+                idx[i] = kMagenta + (uint32_t)row;  // magenta, cyan, yellow, green, red
+            }
+          }
+        }
+      }
+    }
+    // player cannon at ((int)playerX, 170), :388
+    if (layers & kLayerCannon) {
+      const int dy = y - (kScreenH - 40);
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int dx = xg + i - player_x;
+        if ((unsigned)dx < 8u && ((cannon >> (8 * dy + dx)) & 1ull)) idx[i] = kGreen;
+      }
+    }
+    // player bullets (yellow) then alien bullets (red), 2 x 4 pixels each, :391-400
+    if (layers & kLayerPlayerBullets) {
+#pragma unroll
+      for (int b = 0; b < si::kMaxPB; b++)
+        if (b < npb && (unsigned)(y - pby[b]) < 4u) {
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            if ((unsigned)(xg + i - pbx[b]) < 2u) idx[i] = kYellow;
+        }
+    }
+    if (layers & kLayerAlienBullets) {
+#pragma unroll
+      for (int b = 0; b < si::kMaxAB; b++)
+        if (b < nab && (unsigned)(y - aby[b]) < 4u) {
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            if ((unsigned)(xg + i - abx[b]) < 2u) idx[i] = kRed;
+        }
+    }
+    if (layers & kLayerHud) {
+      const int dy = y - 10;
+      // score (white), :403
+      if (dy < 5) {
+        const uint32_t m = (digit_rows[dy][g >> 3] >> (4 * (g & 7))) & 0xFu;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          if ((m >> i) & 1u) idx[i] = kWhite;
+      }
+      // lives (green cannons), :404, 489-495: cannon k covers x in [120 - 10 k, 127 - 10 k]
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int u = (kScreenW - 40) + 7 - (xg + i);
+        if (u >= 0) {
+          const int k = (u * 205) >> 11;  // / 10
+          const int dx = 7 - (u - 10 * k);
+          if (dx >= 0 && k < shown && ((cannon >> (8 * dy + dx)) & 1ull)) idx[i] = kGreen;
+        }
+      }
+    }
+    // ground line, :407-410
+    if (layers & kLayerGround) idx[0] = idx[1] = idx[2] = idx[3] = kGreen;
+
+    U3 v{0u, 0u, 0u};
+    if ((idx[0] | idx[1] | idx[2] | idx[3]) != 0u) v = pack_rgb4(palette(idx[0]), palette(idx[1]), palette(idx[2]), palette(idx[3]));
+    *reinterpret_cast<U3*>(frame + (uint64_t)c * 12) = v;
   }
 }
 
