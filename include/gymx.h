@@ -214,8 +214,11 @@ int gx_vec_step_async(gx_vec* vec, const void* h_actions, void* h_obs, void* h_r
 int gx_vec_wait(gx_vec* vec);
 
 /* VectorEnv.Step -- zero-copy path: actions already on the device, results
- * read through gx_vec_device_view.  `stream` is a hipStream_t or NULL for the
- * context's stream; the call only enqueues. */
+ * read through gx_vec_device_view.  d_actions is int32 or float [gx_view.stride]
+ * (num_envs rounded up to a multiple of four: the kernels read whole 16-byte
+ * vectors, so the padding must be addressable; its values are ignored), 16-byte
+ * aligned.  `stream` is a hipStream_t or NULL for the context's stream; the call
+ * only enqueues. */
 int gx_vec_step_device(gx_vec* vec, const void* d_actions, void* stream);
 /* One step with actions sampled on the device (GX_POLICY_RANDOM). */
 int gx_vec_step_random(gx_vec* vec, void* stream);
