@@ -1,0 +1,79 @@
+"""Random sequences of ABI calls (reset, host-path step, in-kernel-policy step, fused rollout,
+set_state, statistics) on the GPU engine and the same sequence on the oracle: the state after every
+call and the statistics at the end must agree.  Catches what single-feature tests cannot: tick
+accounting across call kinds, alternating sweep direction, derived returns meeting set_state,
+results of the staged host path pending across other calls."""
+import numpy as np
+import pytest
+
+from gpu_common import L, bits, make_pair, random_actions
+
+pytestmark = pytest.mark.gpu
+
+FUSED = L.AUTORESET | L.RECORD_STATS
+CASES = [
+    (L.ENV_CARTPOLE, FUSED, 0, None), (L.ENV_CARTPOLE, L.RECORD_STATS, 9, None), (L.ENV_MOUNTAINCAR, FUSED, 0, None),
+    (L.ENV_PENDULUM, FUSED, 0, None), (L.ENV_ACROBOT, FUSED, 0, None), (L.ENV_FROZENLAKE, FUSED, 0, None),
+    (L.ENV_FROZENLAKE, FUSED | L.SLIPPERY, 0, "8x8"), (L.ENV_TAXI, FUSED | L.TAXI_FULL, 0, None),
+    (L.ENV_CLIFFWALKING, L.AUTORESET, 5, None), (L.ENV_PONG, FUSED, 0, None), (L.ENV_BREAKOUT, L.AUTORESET, 0, None),
+]
+
+
+def _same_state(g, o, env_id, what):
+    gr, gi = g.get_state(); orr, oi = o.get_state()
+    assert np.array_equal(gi, oi), what
+    if gr.size == 0:
+        return
+    if np.array_equal(bits(gr), bits(orr)):
+        return
+    # continuous control: a last-place trig difference may flip a float rounding; bound it and resynchronise
+    assert env_id in (L.ENV_CARTPOLE, L.ENV_MOUNTAINCAR, L.ENV_PENDULUM, L.ENV_ACROBOT), what
+    diff = bits(gr) != bits(orr)
+    assert diff.sum() <= 2 and np.allclose(gr, orr, rtol=1e-5, atol=1e-6), what
+    g.set_state(orr, oi)
+
+
+@pytest.mark.parametrize("env_id,flags,time_limit,rows", CASES)
+def test_random_call_sequences(oracle, env_id, flags, time_limit, rows):
+    n = 257 if env_id in (L.ENV_PONG, L.ENV_BREAKOUT) else 1031
+    g, o = make_pair(oracle, env_id, n, seed=1234 + env_id, flags=flags, time_limit=time_limit, map_rows=rows, base=7)
+    rng = np.random.default_rng(99 + env_id + flags)
+    g.reset(); o.reset()
+    _same_state(g, o, env_id, "reset")
+    for t in range(50):
+        op = rng.choice(["host", "host", "random", "rollout", "set_state", "reset", "stats"], p=[0.3, 0.2, 0.2, 0.1, 0.1, 0.05, 0.05])
+        if op == "host":
+            a = random_actions(rng, env_id, n)
+            _, rew, done, _ = g.step_host(a)
+            orew, odone, _ = o.step(a)
+            assert np.array_equal(done, odone), (t, op)
+            if env_id not in (L.ENV_CARTPOLE, L.ENV_MOUNTAINCAR, L.ENV_PENDULUM, L.ENV_ACROBOT):
+                assert np.array_equal(rew.astype(np.float64), orew), (t, op)
+        elif op == "random":
+            g.step_random(); o.step_random()
+        elif op == "rollout":
+            k = int(rng.integers(2, 6))
+            g.rollout(k)
+            for _ in range(k):
+                o.step_random()
+        elif op == "set_state":
+            # shuffle the envs' states among themselves: valid states, arbitrary counters
+            gr, gi = o.get_state()
+            perm = rng.permutation(n)
+            gr, gi = gr[:, perm].copy(), gi[:, perm].copy()
+            g.set_state(gr, gi); o.set_state(gr, gi)
+        elif op == "reset":
+            g.reset(); o.reset()
+        elif op == "stats" and (flags & L.RECORD_STATS):
+            s, so = g.stats(), o.stats()
+            assert s.episodes == so.episodes and s.sum_length == so.sum_length, (t, op)
+        g.ctx.synchronize()
+        _same_state(g, o, env_id, (t, op))
+        assert g.tick == o.tick, (t, op)
+    if flags & L.RECORD_STATS:
+        s, so = g.stats(), o.stats()
+        assert s.episodes == so.episodes and s.sum_length == so.sum_length
+        assert abs(s.sum_return - so.sum_return) <= 1e-9 * max(1.0, abs(so.sum_return))
+        if so.episodes:
+            assert abs(s.min_return - so.min_return) <= 1e-9 * max(1.0, abs(so.min_return))
+            assert abs(s.max_return - so.max_return) <= 1e-9 * max(1.0, abs(so.max_return))
