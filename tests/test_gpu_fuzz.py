@@ -19,27 +19,42 @@ CASES = [
 ]
 
 
-def _same_state(g, o, env_id, what):
+def _same_state(g, o, env_id, what, fp64=False):
     gr, gi = g.get_state(); orr, oi = o.get_state()
     assert np.array_equal(gi, oi), what
     if gr.size == 0:
         return
+    if fp64:
+        # binary64 mode: held to a tolerance; resynchronise so that rounding differences do not compound
+        assert (np.abs(gr - orr) / np.maximum(np.abs(orr), 1e-6)).max() <= 1e-8, what
+        g.set_state(orr, oi)
+        return
     if np.array_equal(bits(gr), bits(orr)):
         return
     # continuous control: a last-place trig difference may flip a float rounding; bound it and resynchronise
-    assert env_id in (L.ENV_CARTPOLE, L.ENV_MOUNTAINCAR, L.ENV_PENDULUM, L.ENV_ACROBOT), what
+    assert env_id <= L.ENV_ACROBOT, what
     diff = bits(gr) != bits(orr)
     assert diff.sum() <= 2 and np.allclose(gr, orr, rtol=1e-5, atol=1e-6), what
     g.set_state(orr, oi)
 
 
+@pytest.mark.parametrize("env_id", [L.ENV_CARTPOLE, L.ENV_MOUNTAINCAR_CONT, L.ENV_PENDULUM, L.ENV_ACROBOT])
+def test_random_call_sequences_binary64(oracle, env_id):
+    _run_sequence(oracle, env_id, FUSED, 0, None, L.MODE_FP64)
+
+
 @pytest.mark.parametrize("env_id,flags,time_limit,rows", CASES)
 def test_random_call_sequences(oracle, env_id, flags, time_limit, rows):
+    _run_sequence(oracle, env_id, flags, time_limit, rows, L.MODE_EXACT)
+
+
+def _run_sequence(oracle, env_id, flags, time_limit, rows, mode):
+    fp64 = mode == L.MODE_FP64
     n = 257 if env_id in (L.ENV_PONG, L.ENV_BREAKOUT) else 1031
-    g, o = make_pair(oracle, env_id, n, seed=1234 + env_id, flags=flags, time_limit=time_limit, map_rows=rows, base=7)
+    g, o = make_pair(oracle, env_id, n, seed=1234 + env_id, flags=flags, time_limit=time_limit, map_rows=rows, base=7, mode=mode)
     rng = np.random.default_rng(99 + env_id + flags)
     g.reset(); o.reset()
-    _same_state(g, o, env_id, "reset")
+    _same_state(g, o, env_id, "reset", fp64)
     for t in range(50):
         op = rng.choice(["host", "host", "random", "rollout", "set_state", "reset", "stats"], p=[0.3, 0.2, 0.2, 0.1, 0.1, 0.05, 0.05])
         if op == "host":
@@ -47,12 +62,14 @@ def test_random_call_sequences(oracle, env_id, flags, time_limit, rows):
             _, rew, done, _ = g.step_host(a)
             orew, odone, _ = o.step(a)
             assert np.array_equal(done, odone), (t, op)
-            if env_id not in (L.ENV_CARTPOLE, L.ENV_MOUNTAINCAR, L.ENV_PENDULUM, L.ENV_ACROBOT):
+            if env_id > L.ENV_ACROBOT:  # integer and byte work: exact
                 assert np.array_equal(rew.astype(np.float64), orew), (t, op)
+            else:
+                assert np.allclose(rew.astype(np.float64), orew, rtol=1e-5, atol=1e-6), (t, op)
         elif op == "random":
             g.step_random(); o.step_random()
         elif op == "rollout":
-            k = int(rng.integers(2, 6))
+            k = 2 if fp64 else int(rng.integers(2, 6))  # binary64: short, so rounding differences stay far from thresholds
             g.rollout(k)
             for _ in range(k):
                 o.step_random()
@@ -68,7 +85,7 @@ def test_random_call_sequences(oracle, env_id, flags, time_limit, rows):
             s, so = g.stats(), o.stats()
             assert s.episodes == so.episodes and s.sum_length == so.sum_length, (t, op)
         g.ctx.synchronize()
-        _same_state(g, o, env_id, (t, op))
+        _same_state(g, o, env_id, (t, op), fp64)
         assert g.tick == o.tick, (t, op)
     if flags & L.RECORD_STATS:
         s, so = g.stats(), o.stats()
