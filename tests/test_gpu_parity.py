@@ -623,3 +623,51 @@ def test_host_path_both_transports(oracle, env_id, stage_limit, monkeypatch):
     o2, od2, _ = o.step(a2)
     assert np.array_equal(r1.astype(np.float64), o1) and np.array_equal(d1, od1)
     assert np.array_equal(r2.astype(np.float64), o2) and np.array_equal(d2, od2)
+
+
+def test_abi_rejects_bad_arguments_on_the_device():
+    """every entry point that can be misused returns a status and a message; nothing aborts and the batch stays usable"""
+    import ctypes as C
+    from gpu_common import ctx
+    from gym_amd.engine import DeviceBatch
+    lib = L.load()
+    c = ctx()
+
+    def create(**kw):
+        d = L.GxDesc(struct_size=C.sizeof(L.GxDesc), env_id=L.ENV_CARTPOLE, num_envs=8, seed=1, env_index_base=0, mode=L.MODE_EXACT,
+                   flags=0, time_limit=0, reserved=0, map_rows=None)
+        for k, v in kw.items():
+            setattr(d, k, v)
+        h = C.c_void_p()
+        return lib.gx_vec_create(c._h, C.byref(d), C.byref(h)), h
+
+    for bad in (dict(struct_size=8), dict(env_id=99), dict(env_id=-1), dict(num_envs=0), dict(mode=7), dict(time_limit=-1),
+                dict(flags=1 << 20), dict(num_envs=(1 << 31) + 1)):
+        rc, h = create(**bad)
+        assert rc in (L.GX_ERR_INVALID, L.GX_ERR_UNSUPPORTED) and not h.value, bad
+        assert lib.gx_last_error()
+    rc, h = create(env_id=L.ENV_FROZENLAKE, map_rows=b"SF/FFG")
+    assert rc == L.GX_ERR_INVALID and b"map" in lib.gx_last_error()
+
+    g = DeviceBatch(c, L.ENV_CARTPOLE, 10, seed=2)  # no statistics, no time limit
+    g.reset()
+    buf = np.zeros(7, np.uint8)
+    p = buf.ctypes.data_as(C.c_void_p)
+    assert lib.gx_vec_get_state(g._h, p, 7) == L.GX_ERR_INVALID
+    assert lib.gx_vec_set_state(g._h, p, 7) == L.GX_ERR_INVALID
+    assert lib.gx_vec_get_obs(g._h, p, 7) == L.GX_ERR_INVALID
+    st = L.GxStats()
+    assert lib.gx_vec_stats(g._h, C.byref(st)) == L.GX_ERR_INVALID  # created without GX_RECORD_STATS
+    a = np.zeros(10, np.int32)
+    tr = np.zeros(10, np.uint8)
+    assert lib.gx_vec_step_async(g._h, a.ctypes.data_as(C.c_void_p), None, None, None, tr.ctypes.data_as(C.c_void_p)) == L.GX_ERR_INVALID
+    assert lib.gx_vec_step_async(g._h, None, None, None, None, None) == L.GX_ERR_INVALID
+    assert lib.gx_vec_step_device(g._h, None, None) == L.GX_ERR_INVALID
+    assert lib.gx_vec_step_device(g._h, C.c_void_p(g.view().state_int + 4), None) == L.GX_ERR_INVALID  # not 16-byte aligned
+    assert lib.gx_vec_rollout(g._h, 0, L.POLICY_RANDOM, None, None) == L.GX_ERR_INVALID
+    assert lib.gx_vec_rollout(g._h, 4, 9, None, None) == L.GX_ERR_INVALID
+    assert lib.gx_vec_rollout(g._h, 4, L.POLICY_DEVICE_ACTIONS, None, None) == L.GX_ERR_INVALID
+    assert lib.gx_vec_sample_actions(g._h, 0, None, None) == L.GX_ERR_INVALID
+    # still usable afterwards
+    _, rew, done, _ = g.step_host(np.ones(10, np.int32))
+    assert rew.shape == (10,) and not done.any()
