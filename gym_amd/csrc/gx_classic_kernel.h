@@ -130,6 +130,45 @@ struct ThreadStats<double> {
   __device__ __forceinline__ StatAcc widen() const { return acc; }
 };
 
+// Integer-valued returns in the kernels that sample their own actions (the fused rollouts and the
+// in-kernel-policy step): every lane keeps its record in LDS (field-major, so a wave's access to
+// one field is conflict-free) and adds to it with return-less LDS atomics when one of its envs
+// finishes an episode.  No accumulator registers are carried through the kernel; at its end a lane
+// reads its record back and the wave reduces as usual.  Measured against the register form:
+// CartPole K = 64 rollout 3.54 -> 3.41 ms, in-kernel-policy step 0.1405 -> 0.1343 ms; the step with
+// actions read from memory does not gain and keeps the registers.
+struct LaneStatsLds {
+  unsigned long long sum_length[kClassicBlock], sum_return[kClassicBlock], sum_return_sq[kClassicBlock];  // two's complement
+  uint32_t episodes[kClassicBlock];
+  int32_t min_return[kClassicBlock], max_return[kClassicBlock];
+};
+__device__ __forceinline__ void lane_stats_init(LaneStatsLds& w) {
+  const int l = threadIdx.x;
+  w.sum_length[l] = w.sum_return[l] = w.sum_return_sq[l] = 0ull;
+  w.episodes[l] = 0u;
+  w.min_return[l] = 0x7FFFFFFF;
+  w.max_return[l] = (int32_t)0x80000000;
+}
+__device__ __forceinline__ void lane_stats_add(LaneStatsLds& w, int32_t ret, int32_t len) {
+  const int l = threadIdx.x;
+  atomicAdd(&w.episodes[l], 1u);
+  atomicAdd(&w.sum_length[l], (unsigned long long)(long long)len);
+  atomicAdd(&w.sum_return[l], (unsigned long long)(long long)ret);
+  atomicAdd(&w.sum_return_sq[l], (unsigned long long)((long long)ret * ret));
+  atomicMin(&w.min_return[l], ret);
+  atomicMax(&w.max_return[l], ret);
+}
+__device__ __forceinline__ StatAcc lane_stats_read(const LaneStatsLds& w) {
+  const int l = threadIdx.x;
+  StatAcc a;
+  a.episodes = w.episodes[l];
+  a.sum_length = (long long)w.sum_length[l];
+  a.sum_return = (double)(long long)w.sum_return[l];
+  a.sum_return_sq = (double)(long long)w.sum_return_sq[l];
+  if (a.episodes) { a.min_return = (double)w.min_return[l]; a.max_return = (double)w.max_return[l]; }
+  return a;
+}
+
 // ---------------------------------------------------------------- kernels ---
 // E::kStepReturn of an env whose rewards differ from step to step
 constexpr int kNoStepReturn = 0x7FFFFFFF;
@@ -175,7 +214,11 @@ __global__ void __launch_bounds__(kClassicBlock, (FUSED && BOUNDED) ? GX_FUSED_M
   // on every non-final step is that constant times the step counter: the row is neither read
   // nor written (8 bytes per env-step less), the statistics come out the same.
   const bool derive_returns = FUSED && E::kStepReturn != kNoStepReturn && a.derive_returns != 0;
+  constexpr bool kLdsStats = std::is_same<EpRet, int32_t>::value && POLICY == GX_POLICY_RANDOM;
+  static_assert(kClassicBlock == 64, "a lane's LDS statistics record is indexed by threadIdx.x");
+  __shared__ LaneStatsLds lane_stats;
   ThreadStats<EpRet> acc;
+  if (kLdsStats && record) lane_stats_init(lane_stats);
 
   const uint64_t ngroups = (a.num_envs + (W - 1)) / W;
   for (uint64_t it = (uint64_t)blockIdx.x * kClassicBlock + threadIdx.x; it < ngroups; it += (uint64_t)gridDim.x * kClassicBlock) {
@@ -243,7 +286,12 @@ __global__ void __launch_bounds__(kClassicBlock, (FUSED && BOUNDED) ? GX_FUSED_M
           // EnvWrapper.cs:46-55
           ep_ret[j] += (EpRet)reward[j];
           ep_len[j] += 1;
-          acc.add(d && q * W + j < a.num_envs, ep_ret[j], ep_length_row ? ep_len[j] : steps[j]);
+          const bool finished = d && q * W + j < a.num_envs;
+          if constexpr (kLdsStats) {
+            if (finished) lane_stats_add(lane_stats, (int32_t)ep_ret[j], ep_length_row ? ep_len[j] : steps[j]);
+          } else {
+            acc.add(finished, ep_ret[j], ep_length_row ? ep_len[j] : steps[j]);
+          }
           ep_ret[j] = d ? (EpRet)0 : ep_ret[j];
           ep_len[j] = d ? 0 : ep_len[j];
         }
@@ -300,7 +348,10 @@ __global__ void __launch_bounds__(kClassicBlock, (FUSED && BOUNDED) ? GX_FUSED_M
       }
     }
   }
-  if (record) block_commit_stats(acc.widen(), a.stat_slots);
+  if (record) {
+    if constexpr (kLdsStats) block_commit_stats(lane_stats_read(lane_stats), a.stat_slots);
+    else block_commit_stats(acc.widen(), a.stat_slots);
+  }
 }
 
 // Reset() of every env, or (when only_observe) just the derived observation
