@@ -139,11 +139,15 @@ GX_HD void sincos_bounded(double x, double& s, double& c) {
 GX_HD void sincos_reduced(double x, double& s, double& c) {
   const double INV_PIO2 = 0x1.45f306dc9c883p-1;
   const double P1 = 0x1.921fb54400000p+0, P2 = 0x1.0b4611a626331p-34;
-  const double fn = rint(x * INV_PIO2);
+  // round(x * 2/pi) by adding and subtracting 1.5 * 2^52: the sum's low mantissa bits are the
+  // quadrant number, so neither a rounding instruction nor a float-to-int conversion is needed
+  const double MAGIC = 0x1.8p+52;
+  const double t = fma(x, INV_PIO2, MAGIC);
+  const double fn = t - MAGIC;
   const double r = fma(-fn, P2, fma(-fn, P1, x));
   double sn, cs;
   sincos_small(r, sn, cs);
-  quadrant((int)fn, sn, cs, s, c);
+  quadrant((int)(uint32_t)f64_bits(t), sn, cs, s, c);
 }
 
 // 1 / x in binary64 to the last place or two (hardware estimate plus two Newton steps), for the
