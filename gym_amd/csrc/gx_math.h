@@ -107,7 +107,10 @@ GX_HD void sincos_bounded(double x, double& s, double& c) {
                S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
   const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
                C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-  const double fn = rint(x * INV_PIO2);
+  // round(x * 2/pi) by adding and subtracting 1.5 * 2^52; the quadrant number is in the sum's low bits
+  const double MAGIC = 0x1.8p+52;
+  const double tq = fma(x, INV_PIO2, MAGIC);
+  const double fn = tq - MAGIC;
   const double r0 = fma(-fn, P1, x);           // exact
   const double r = fma(-fn, P2, r0);           // head of the reduced argument
   double t = fma(-fn, P2, r0 - r);             // what the rounding of r dropped
@@ -128,7 +131,7 @@ GX_HD void sincos_bounded(double x, double& s, double& c) {
   const double hz = 0.5 * z;
   const double w = 1.0 - hz;
   const double cs = w + (((1.0 - w) - hz) + fma(z * z, rc, -(r * t)));
-  quadrant((int)fn, sn, cs, s, c);
+  quadrant((int)(uint32_t)f64_bits(tq), sn, cs, s, c);
 }
 
 // sin(x) and cos(x) in binary64 to a few units in the last place, for |x| up to
