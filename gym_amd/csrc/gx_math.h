@@ -51,7 +51,6 @@ GX_HD void quadrant(int q, double sn, double cs, double& s, double& c) {
   c = f64_from_bits(((uint64_t)(bh ^ sign_c) << 32) | bl);
 }
 
-// sin(x) and cos(x) in binary64 for |x| <= pi/4, no argument reduction.
 // a * b + k for a compile-time constant k.  Written as one v_fma_f64 with the constant in a scalar
 // register pair: left to itself the compiler puts such a constant into a vector register pair
 // (two moves) and accumulates into it, three vector instructions per polynomial term.
@@ -65,6 +64,7 @@ GX_HD double fma_k(double a, double b, double k) {
 #endif
 }
 
+// sin(x) and cos(x) in binary64 for |x| <= pi/4, no argument reduction.
 // Minimax kernels of the classic fdlibm form (sin: x + x^3 S(x^2), cos:
 // 1 - x^2/2 + x^4 C(x^2)) evaluated by Horner's rule with fused multiply-adds;
 // the error stays under one unit in the last place of the double, so rounding
