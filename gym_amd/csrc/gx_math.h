@@ -120,17 +120,16 @@ GX_HD void sincos_bounded(double x, double& s, double& c) {
   rs = fma_k(z, rs, S4);
   rs = fma_k(z, rs, S3);
   rs = fma_k(z, rs, S2);
-  const double v = z * r;
-  // r - ((z (t/2 - v rs) - t) - v S1)
-  const double sn = r - (fma(z, fma(0.5, t, -(v * rs)), -t) - v * S1);
+  rs = fma_k(z, rs, S1);
+  // sin(r + t) = sin r + t cos r: r + r^3 S(z) rounds once, t (1 - z/2) is below 2^-53 of it
+  const double sn = fma(t, fma(-0.5, z, 1.0), fma(z * r, rs, r));
   double rc = fma_k(z, C6, C5);
   rc = fma_k(z, rc, C4);
   rc = fma_k(z, rc, C3);
   rc = fma_k(z, rc, C2);
   rc = fma_k(z, rc, C1);
-  const double hz = 0.5 * z;
-  const double w = 1.0 - hz;
-  const double cs = w + (((1.0 - w) - hz) + fma(z * z, rc, -(r * t)));
+  // cos(r + t) = cos r - t sin r: 1 + z (-1/2 + z rc) rounds once, r t is below 2^-53
+  const double cs = fma(-r, t, fma(z, fma_k(z, rc, -0.5), 1.0));
   quadrant((int)(uint32_t)f64_bits(tq), sn, cs, s, c);
 }
 
