@@ -175,12 +175,15 @@ GX_HD double rcp64(double x) {
 // polynomial term is a single v_fma_f64 (see fma_k).
 GX_HD double atan2_f64(double y, double x) {
   const double ax = fabs(x), ay = fabs(y);
-  const double mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+  // fmax / fmin drop a NaN operand; NaN arguments are put back at the end
+  const double mx = fmax(ax, ay), mn = fmin(ax, ay);
   const double r = rcp64(mx);
   double q = mn * r;
   q = fma(fma(-q, mx, mn), r, q);
-  // 0 / 0 -> 0 (the angle then depends on the signs alone), inf / inf -> 1, finite / inf -> 0
-  if (!(mx > 0.0 && mx < __builtin_huge_val())) q = (mn == mx && mx > 0.0) ? 1.0 : ((mx != mx || mn != mn) ? mx + mn : 0.0);
+  // the quotient comes out NaN exactly when the larger magnitude is 0 (0 times inf) or infinite
+  // (a product of 0 and inf in the residual): 0 / 0 -> 0 (the angle then depends on the signs alone),
+  // inf / inf -> 1, finite / inf -> 0
+  if (q != q) q = (mn == mx && mx != 0.0) ? 1.0 : 0.0;
   const double t = q * q;
   double p = fma_k(t, -0x1.8d087295ab9f4p-17, 0x1.1f0adb240a1fbp-13);
   p = fma_k(t, p, -0x1.8a2f3ae537bb1p-11);
@@ -207,7 +210,8 @@ GX_HD double atan2_f64(double y, double x) {
   const double PIO2_HI = 0x1.921fb54442d18p+0, PIO2_LO = 0x1.1a62633145c07p-54;
   a = ay > ax ? (PIO2_HI - (a - PIO2_LO)) : a;
   a = __builtin_signbit(x) ? (2.0 * PIO2_HI - (a - 2.0 * PIO2_LO)) : a;
-  return copysign(a, y);
+  a = copysign(a, y);
+  return (x != x || y != y) ? x + y : a;
 }
 
 // ---- binary32 routines of the FAST32 mode (held to 1e-5 relative, not to the last bit) ----
