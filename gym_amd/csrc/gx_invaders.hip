@@ -1,8 +1,7 @@
 // SpaceInvaders: game state stepped one env per lane in binary64, and the
-// 210x160x3 frame of every env painted by a workgroup into a four-bit-per-
-// pixel palette image in LDS (16.8 KB, so eight workgroups fit a CU), in the
-// reference's own drawing order, then expanded to RGB with coalesced 12-byte
-// stores.
+// 210x160x3 frame of every env written by a workgroup, each lane deciding four
+// pixels at a time from the game state (the layers applied in the reference's
+// own drawing order) and storing them as twelve coalesced bytes.
 //
 // The reference keeps its bullets in List<(double,double)>
 // (Envs.SpaceInvaders.cs:35-36).  Player bullets are capped at three by the
