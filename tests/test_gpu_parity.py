@@ -671,3 +671,38 @@ def test_abi_rejects_bad_arguments_on_the_device():
     # still usable afterwards
     _, rew, done, _ = g.step_host(np.ones(10, np.int32))
     assert rew.shape == (10,) and not done.any()
+
+
+@pytest.mark.parametrize("env_id", [L.ENV_CARTPOLE, L.ENV_PENDULUM, L.ENV_ACROBOT, L.ENV_FROZENLAKE, L.ENV_TAXI, L.ENV_PONG, L.ENV_BREAKOUT])
+def test_rollout_with_device_action_rows(oracle, env_id):
+    """gx_vec_rollout(K, DEVICE_ACTIONS, d_actions[K][stride]): K fused steps with the actions read from a
+    device array equal K oracle steps with the same actions (also: a ragged batch, the padded stride)"""
+    import torch
+    n, k = (259 if env_id in (L.ENV_PONG, L.ENV_BREAKOUT) else 4099), 7
+    flags = L.AUTORESET | L.RECORD_STATS
+    g, o = make_pair(oracle, env_id, n, seed=51, flags=flags)
+    g.reset(); o.reset()
+    stride = int(g.view().stride)
+    assert stride >= n and stride % 4 == 0
+    rng = np.random.default_rng(env_id + 5)
+    acts = np.stack([random_actions(rng, env_id, n) for _ in range(k)])
+    host = np.zeros((k, stride), acts.dtype)
+    host[:, :n] = acts
+    dev = torch.from_numpy(host).cuda()
+    for rounds in range(2):  # two rollouts back to back: the sweep direction alternates
+        g.rollout(k, L.POLICY_DEVICE_ACTIONS, dev.data_ptr())
+        g.ctx.synchronize()
+        for t in range(k):
+            o.step(acts[t])
+        gr, gi = g.get_state(); orr, oi = o.get_state()
+        assert np.array_equal(gi, oi), rounds
+        if gr.size:
+            if env_id <= L.ENV_ACROBOT:
+                assert (bits(gr) != bits(orr)).sum() <= 2 and np.allclose(gr, orr, rtol=1e-4, atol=1e-5), rounds
+                g.set_state(orr, oi)
+            else:
+                assert np.array_equal(bits(gr), bits(orr)), rounds
+    s, so = g.stats(), o.stats()
+    assert s.episodes == so.episodes and s.sum_length == so.sum_length
+    if env_id in (L.ENV_PONG, L.ENV_BREAKOUT):
+        assert np.array_equal(g.get_obs(), o.get_obs())
