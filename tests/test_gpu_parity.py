@@ -706,3 +706,29 @@ def test_rollout_with_device_action_rows(oracle, env_id):
     assert s.episodes == so.episodes and s.sum_length == so.sum_length
     if env_id in (L.ENV_PONG, L.ENV_BREAKOUT):
         assert np.array_equal(g.get_obs(), o.get_obs())
+
+
+@pytest.mark.parametrize("env_id", [L.ENV_CARTPOLE, L.ENV_MOUNTAINCAR_CONT, L.ENV_TAXI, L.ENV_SPACEINVADERS])
+def test_sampled_actions_replay_the_in_kernel_policy(oracle, env_id):
+    """gx_vec_sample_actions gives the draws the in-kernel policy makes at a tick: they equal the oracle's,
+    and stepping with them through the zero-copy path, on a caller's stream, equals gx_vec_step_random"""
+    import torch
+    n = 263 if env_id == L.ENV_SPACEINVADERS else 5003
+    a, o = make_pair(oracle, env_id, n, seed=61, flags=L.AUTORESET, base=11)
+    b, _ = make_pair(oracle, env_id, n, seed=61, flags=L.AUTORESET, base=11)
+    a.reset(); b.reset(); o.reset()
+    stride = int(a.view().stride)
+    adt = torch.float32 if a.info.action_dtype == L.F32 else torch.int32
+    dev = torch.zeros(stride, dtype=adt, device="cuda")
+    stream = torch.cuda.Stream()
+    for t in range(6):
+        tick = a.tick
+        a.sample_actions(tick, dev.data_ptr(), stream.cuda_stream)
+        a.step_device(dev.data_ptr(), stream.cuda_stream)
+        stream.synchronize()
+        b.step_random()
+        b.ctx.synchronize()
+        oa, _, _, _ = o.step_random()
+        assert np.array_equal(bits(dev[:n].cpu().numpy()), bits(oa)), t
+        ar, ai = a.get_state(); br, bi = b.get_state()
+        assert np.array_equal(ai, bi) and np.array_equal(bits(ar), bits(br)), t
