@@ -94,3 +94,27 @@ def _run_sequence(oracle, env_id, flags, time_limit, rows, mode):
         if so.episodes:
             assert abs(s.min_return - so.min_return) <= 1e-9 * max(1.0, abs(so.min_return))
             assert abs(s.max_return - so.max_return) <= 1e-9 * max(1.0, abs(so.max_return))
+
+
+def test_batches_sharing_a_context_do_not_interfere(oracle):
+    """three batches on one context (one stream pair, one staging path each), stepped in turns"""
+    specs = [(L.ENV_CARTPOLE, 1000, 3), (L.ENV_CARTPOLE, 37, 4), (L.ENV_FROZENLAKE, 513, 5), (L.ENV_PONG, 65, 6)]
+    pairs = [make_pair(oracle, e, n, seed=s, flags=FUSED) for e, n, s in specs]
+    for g, o in pairs:
+        g.reset(); o.reset()
+    rng = np.random.default_rng(8)
+    for t in range(25):
+        for idx in rng.permutation(len(pairs)):
+            (g, o), (e, n, _) = pairs[idx], specs[idx]
+            if rng.random() < 0.5:
+                a = random_actions(rng, e, n)
+                _, _, done, _ = g.step_host(a)
+                _, odone, _ = o.step(a)
+                assert np.array_equal(done, odone), (t, idx)
+            else:
+                g.step_random(); o.step_random()
+    for (g, o), (e, n, _) in zip(pairs, specs):
+        g.ctx.synchronize()
+        _same_state(g, o, e, "end")
+        s, so = g.stats(), o.stats()
+        assert s.episodes == so.episodes and s.sum_length == so.sum_length
