@@ -8,8 +8,12 @@ numeric mode.  State, actions and outputs are resident in HBM before the
 timed region starts.
 
   python bench.py --gpus 1 --steps 200 --warmup 20
+  python bench.py --gpus N ...            (starts its own N ranks, one per GPU)
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
+Started plainly with --gpus N > 1 (no WORLD_SIZE in the environment) this process only launches
+N fresh children of the same script with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relays
+rank 0's JSON line and exits with the worst exit code; it never imports torch or touches a GPU.
 Rank 0 prints one JSON line.  The batch is sharded by env index (RNG streams
 are keyed by the global index); there is no collective in the step path, and
 episode statistics are all-reduced once over RCCL after the timed region.
@@ -23,6 +27,58 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+
+def _gpus_from_argv(argv):
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            return int(argv[i + 1])
+        if a.startswith("--gpus="):
+            return int(a.split("=", 1)[1])
+    return 1
+
+
+def spawn_ranks(world, argv):
+    """One child process per rank, each a fresh interpreter that initialises its own GPU.  Returns
+    the worst exit code.  When a rank fails the others (which would wait for it at a barrier for
+    ever) are given a short grace period and then terminated, each by its own PID."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out = procs[0].stdout.read()  # rank 0 is the only one that prints; ends when it exits
+    sys.stdout.write(out.decode("utf-8", "replace"))
+    sys.stdout.flush()
+    worst, deadline = 0, None
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            rc = p.poll()
+            if rc is not None:
+                pending.remove(p)
+                if rc != 0:
+                    worst = worst or (rc if rc > 0 else 128 - rc)
+                    deadline = deadline or time.time() + 30.0
+        if pending and deadline and time.time() > deadline:
+            for p in pending:
+                p.terminate()
+            deadline = time.time() + 1e9
+        time.sleep(0.05)
+    return worst
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ and _gpus_from_argv(sys.argv[1:]) > 1:
+    # the launcher: before torch is imported, before anything can touch a GPU
+    sys.exit(spawn_ranks(_gpus_from_argv(sys.argv[1:]), sys.argv[1:]))
+
 import torch  # noqa: E402  (device memory, streams, events, torch.distributed only)
 
 from gym_amd import _lib as L  # noqa: E402
@@ -30,6 +86,7 @@ from gym_amd.distributed import allreduce_stats, shard  # noqa: E402
 from gym_amd.engine import Context, DeviceBatch  # noqa: E402
 
 COLLECTIVE_DEVICE = "cuda"   # tensors handed to torch.distributed live here (cpu for the gloo rehearsal)
+ACTION_RING = 8              # pre-sampled action rows the device-actions policy cycles through
 HBM_PEAK_GBPS = 8000.0       # MI355X HBM3E peak
 FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X vector FP64 peak
 
@@ -235,10 +292,19 @@ def main():
                 torch.cuda.current_stream().synchronize()
                 allreduce_stats(batch.stats(), dist, device=COLLECTIVE_DEVICE)
     elif args.policy == "device":
+        # a ring of pre-sampled action rows, ActionSpace.Sample() of ticks 0..7, cycled step by step:
+        # the policy is random in time as well as across envs, and a step still reads one 4-byte
+        # action per env
         adt = torch.float32 if batch.info.action_dtype == L.F32 else torch.int32
-        actions = torch.empty(int(view.stride), dtype=adt, device="cuda")
-        batch.sample_actions(0, actions.data_ptr(), stream_ptr)
-        step_fn = lambda: batch.step_device(actions.data_ptr(), stream_ptr)  # noqa: E731
+        ring = torch.empty((ACTION_RING, int(view.stride)), dtype=adt, device="cuda")
+        for t in range(ACTION_RING):
+            batch.sample_actions(t, ring[t].data_ptr(), stream_ptr)
+        ring_ptrs = [ring[t].data_ptr() for t in range(ACTION_RING)]
+        turn = [0]
+
+        def step_fn():
+            batch.step_device(ring_ptrs[turn[0] % ACTION_RING], stream_ptr)
+            turn[0] += 1
     else:
         step_fn = lambda: batch.step_random(stream_ptr)  # noqa: E731
     torch.cuda.synchronize()
@@ -269,7 +335,7 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": "%s VectorEnv.Step, %d envs/GPU, %s, auto-reset + RecordEpisodeStatistics fused, "
-                        "%s, %s mode" % (name, n, kind, "device-resident random actions (zero-copy path)"
+                        "%s, %s mode" % (name, n, kind, "device-resident random actions, a ring of %d pre-sampled rows cycled per step (zero-copy path)" % ACTION_RING
                                          if args.policy == "device" else "actions sampled in-kernel", args.mode),
             "envs_per_gpu": n, "sharding": "independent env shards, no data-path collective",
         },
@@ -293,10 +359,17 @@ def main():
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(traffic_file) and world == 1:
         try:
+            from gym_amd.build import csrc_hash
+
             t = json.load(open(traffic_file)).get("%s:%d:%s" % (args.env, n, args.policy))
-            if t and not args.rk4 and k_roll == 1:
-                out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
-                out["roofline"]["traffic_source"] = t["source"]
+            if t and not args.rk4 and k_roll == 1 and not (args.slippery or args.taxi_full or args.map or args.mode != "exact"):
+                if t.get("csrc_hash") == csrc_hash():
+                    out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+                    out["roofline"]["traffic_source"] = t["source"]
+                else:
+                    # counters taken on other kernel sources say nothing about this build
+                    print("note: profiles/traffic.json was measured on kernel sources %s, this build is %s; traffic left null"
+                          % (t.get("csrc_hash"), csrc_hash()), file=sys.stderr)
         except (OSError, ValueError, KeyError):
             pass
 

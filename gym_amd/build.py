@@ -22,6 +22,20 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function"]
 
 
+def csrc_hash():
+    """Short hash of the kernel and ABI sources: stamps measurements (profiles/traffic.json) with the
+    code they were taken on."""
+    import hashlib
+
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip", ".cpp")))
+    files.append(os.path.join(os.path.dirname(HERE), "include", "gymx.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _deps():
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "gymx.h"))
