@@ -17,6 +17,7 @@ GX_OK, GX_ERR_INVALID, GX_ERR_HIP, GX_ERR_OOM, GX_ERR_UNSUPPORTED, GX_ERR_RCCL =
 MODE_EXACT, MODE_FAST32, MODE_FP64 = 0, 1, 2
 AUTORESET, RECORD_STATS, SLIPPERY, TAXI_FULL, ACROBOT_RK4 = 1, 2, 4, 8, 16
 POLICY_DEVICE_ACTIONS, POLICY_RANDOM = 0, 1
+OUT_LAST, OUT_ALL, OUT_NONE = 0, 1, 2
 F32, F64, I32, U8 = range(4)
 
 
@@ -80,6 +81,7 @@ SIGNATURES = {
     "gx_vec_step_random": (_i, [_vp, _vp]),
     "gx_vec_device_view": (_i, [_vp, C.POINTER(GxView)]),
     "gx_vec_rollout": (_i, [_vp, _i, _i, _vp, _vp]),
+    "gx_vec_rollout_out": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "gx_vec_sample_actions": (_i, [_vp, _u64, _vp, _vp]),
     "gx_vec_tick": (_i, [_vp, C.POINTER(_u64)]),
     "gx_vec_stats": (_i, [_vp, C.POINTER(GxStats)]),

@@ -85,10 +85,19 @@ struct Acrobot64 {
     dy[0] = w1; dy[1] = w2; dy[2] = a1; dy[3] = a2;
   }
 
+  // Into [-pi, pi] in bounded time.  A step moves an angle by less than two turns (the velocities
+  // are bounded by 9 pi and dt = 0.2), so two single-turn corrections -- each the exact
+  // `x -= two_pi` a loop would make -- cover every state the env itself produces; anything still
+  // outside (a huge angle written by a caller) is reduced in one multiply-add, and a non-finite
+  // value ends as NaN instead of keeping a loop alive.
   static __device__ __forceinline__ double wrap_pi(double x) {
     const double two_pi = 2.0 * M_PI;
-    while (x > M_PI) x -= two_pi;
-    while (x < -M_PI) x += two_pi;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      if (x > M_PI) x -= two_pi;
+      else if (x < -M_PI) x += two_pi;
+    }
+    if (!(fabs(x) <= M_PI)) x = fma(-two_pi, rint(x * (1.0 / two_pi)), x);
     return x;
   }
 

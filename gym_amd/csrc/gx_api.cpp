@@ -50,6 +50,7 @@ struct gx_ctx {
   hipStream_t copy = nullptr;
   hipEvent_t ev_in = nullptr;
   hipEvent_t ev_out = nullptr;
+  int live_handles = 0;     // batches and communicators created on this context and not yet destroyed
 };
 
 struct gx_vec {
@@ -95,6 +96,7 @@ struct gx_vec {
   // set by set_state: the state may violate the invariants the BOUNDED kernels rely on
   // until one step with auto-reset has run
   bool state_dirty = false;
+  hipStream_t last_stream = nullptr;  // the stream of the most recent step launch (gx_vec_wait orders itself after it)
   uint32_t sweep_parity = 0;  // flips every step launch: alternate launches sweep in opposite directions
   // the open-episode return is ret_per_step x the step counter and its row is not maintained
   // (fused auto-reset + statistics on CartPole, MountainCar, Acrobot); ends at the first set_state
@@ -164,6 +166,9 @@ extern "C" int gx_ctx_create(int device, gx_ctx** out) {
 
 extern "C" int gx_ctx_destroy(gx_ctx* c) {
   if (!c) return GX_OK;
+  // a batch's destructor synchronises this context's streams: the context must outlive it
+  if (c->live_handles > 0)
+    return fail(GX_ERR_INVALID, "gx_ctx_destroy: %d batch(es) / communicator(s) of this context are still alive; destroy them first", c->live_handles);
   (void)hipSetDevice(c->device);
   if (c->ev_in) (void)hipEventDestroy(c->ev_in);
   if (c->ev_out) (void)hipEventDestroy(c->ev_out);
@@ -454,8 +459,23 @@ StepArgs make_args(const gx_vec* v, const void* d_actions, int k_steps, uint64_t
   return a;
 }
 
-int launch_step(gx_vec* v, const void* d_actions, int k_steps, uint64_t action_stride, int policy, hipStream_t stream) {
+// per-step output rows of a rollout (gx_vec_rollout_out)
+struct StepOut {
+  void* reward = nullptr;
+  uint8_t* done = nullptr;
+  uint8_t* truncated = nullptr;
+  bool skip_last = false;
+};
+
+int launch_step(gx_vec* v, const void* d_actions, int k_steps, uint64_t action_stride, int policy, hipStream_t stream,
+                const StepOut* out = nullptr) {
   StepArgs a = make_args(v, d_actions, k_steps, action_stride);
+  if (out) {
+    a.out_reward = out->reward;
+    a.out_done = out->done;
+    a.out_truncated = out->truncated;
+    a.skip_last = out->skip_last ? 1 : 0;
+  }
   hipError_t e;
   const uint32_t both = GX_AUTORESET | GX_RECORD_STATS;
   const bool fused = (v->desc.flags & both) == both && v->desc.time_limit == 0;
@@ -473,6 +493,7 @@ int launch_step(gx_vec* v, const void* d_actions, int k_steps, uint64_t action_s
   v->tick += (uint64_t)k_steps;
   v->state_dirty = false;
   v->sweep_parity ^= 1u;
+  v->last_stream = stream;
   return GX_OK;
 }
 
@@ -519,6 +540,7 @@ extern "C" int gx_vec_destroy(gx_vec* v) {
   if (v->h_error) (void)hipHostFree(v->h_error);
   if (v->h_stage) (void)hipHostFree(v->h_stage);
   if (v->h_stat) (void)hipHostFree(v->h_stat);
+  if (v->ctx) v->ctx->live_handles--;
   delete v;
   return GX_OK;
 }
@@ -540,6 +562,7 @@ extern "C" int gx_vec_create(gx_ctx* ctx, const gx_desc* desc, gx_vec** out) {
   gx_vec* v = new (std::nothrow) gx_vec();
   if (!v) return fail(GX_ERR_OOM, "gx_vec_create: host allocation failed");
   v->ctx = ctx;
+  ctx->live_handles++;
   v->desc = *desc;
   if (desc->map_rows) v->map = desc->map_rows;
   v->desc.map_rows = nullptr;
@@ -741,6 +764,18 @@ extern "C" int gx_vec_get_state(gx_vec* v, void* host, size_t bytes) {
 extern "C" int gx_vec_set_state(gx_vec* v, const void* host, size_t bytes) {
   if (!v || !host) return fail(GX_ERR_INVALID, "gx_vec_set_state: null argument");
   if (bytes != v->info.state_bytes) return fail(GX_ERR_INVALID, "gx_vec_set_state: buffer is %zu bytes, state image is %llu", bytes, (unsigned long long)v->info.state_bytes);
+  if (v->is_acrobot64) {
+    // This env keeps its angles wrapped to [-pi, pi] and evaluates sin/cos with a reduction that
+    // is only valid for moderate arguments: an image must hold finite values and angles within
+    // 1024 rad (the first step wraps them).
+    const double* h = static_cast<const double*>(host);
+    for (uint64_t i = 0; i < 4 * v->n; i++) {
+      const bool angle = i < 2 * v->n;
+      if (!std::isfinite(h[i]) || (angle && std::fabs(h[i]) > 1024.0))
+        return fail(GX_ERR_INVALID, "gx_vec_set_state: component %llu of env %llu is %g; the RK4 Acrobot takes finite values and angles within 1024 rad",
+                    (unsigned long long)(i / v->n), (unsigned long long)(i % v->n), h[i]);
+    }
+  }
   gx_ctx* c = v->ctx;
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipStreamSynchronize(c->compute));
@@ -893,6 +928,8 @@ extern "C" int gx_vec_wait(gx_vec* v) {
     if (rc) return rc;
   }
   HIP_TRY(hipStreamSynchronize(c->compute));
+  // steps enqueued on a caller's stream may still be running: the flag is read (and cleared) after them
+  if (v->last_stream && v->last_stream != c->compute) HIP_TRY(hipStreamSynchronize(v->last_stream));
   if (has_error_flag(v)) HIP_TRY(hipMemcpyAsync(v->h_error, v->d_error, 4, hipMemcpyDeviceToHost, c->copy));
   HIP_TRY(hipStreamSynchronize(c->copy));
   if (has_error_flag(v) && *v->h_error) {
@@ -927,6 +964,32 @@ extern "C" int gx_vec_rollout(gx_vec* v, int k_steps, int policy, const void* d_
   }
   HIP_TRY(hipSetDevice(v->ctx->device));
   return launch_step(v, d_actions, k_steps, v->stride, policy, stream ? (hipStream_t)stream : v->ctx->compute);
+}
+
+extern "C" int gx_vec_rollout_out(gx_vec* v, int k_steps, int policy, const void* d_actions, int out, void* d_reward_rows,
+                                  uint8_t* d_done_rows, uint8_t* d_truncated_rows, void* stream) {
+  if (!v) return fail(GX_ERR_INVALID, "gx_vec_rollout_out: null batch");
+  if (k_steps <= 0) return fail(GX_ERR_INVALID, "gx_vec_rollout_out: k_steps must be positive");
+  if (policy != GX_POLICY_RANDOM && policy != GX_POLICY_DEVICE_ACTIONS) return fail(GX_ERR_INVALID, "gx_vec_rollout_out: unknown policy %d", policy);
+  if (policy == GX_POLICY_DEVICE_ACTIONS) {
+    if (!d_actions) return fail(GX_ERR_INVALID, "gx_vec_rollout_out: DEVICE_ACTIONS needs d_actions[k_steps][stride]");
+    if ((uintptr_t)d_actions & 15) return fail(GX_ERR_INVALID, "gx_vec_rollout_out: d_actions must be 16-byte aligned");
+  }
+  StepOut o;
+  switch (out) {
+    case GX_OUT_LAST: break;
+    case GX_OUT_NONE: o.skip_last = true; break;
+    case GX_OUT_ALL:
+      if (!d_reward_rows || !d_done_rows) return fail(GX_ERR_INVALID, "gx_vec_rollout_out: GX_OUT_ALL needs reward and done rows [k_steps][stride]");
+      if (d_truncated_rows && !v->d_trunc) return fail(GX_ERR_INVALID, "gx_vec_rollout_out: truncated rows requested but the batch has no time limit");
+      if (((uintptr_t)d_reward_rows | (uintptr_t)d_done_rows | (uintptr_t)d_truncated_rows) & 15)
+        return fail(GX_ERR_INVALID, "gx_vec_rollout_out: output rows must be 16-byte aligned");
+      o.reward = d_reward_rows; o.done = d_done_rows; o.truncated = d_truncated_rows;
+      break;
+    default: return fail(GX_ERR_INVALID, "gx_vec_rollout_out: unknown output mode %d", out);
+  }
+  HIP_TRY(hipSetDevice(v->ctx->device));
+  return launch_step(v, d_actions, k_steps, v->stride, policy, stream ? (hipStream_t)stream : v->ctx->compute, &o);
 }
 
 extern "C" int gx_vec_sample_actions(gx_vec* v, uint64_t tick, void* d_actions, void* stream) {
@@ -1013,6 +1076,7 @@ extern "C" int gx_comm_destroy(gx_comm* m) {
   }
   if (m->d_buf) (void)hipFree(m->d_buf);
   if (m->h_buf) (void)hipHostFree(m->h_buf);
+  if (m->ctx) m->ctx->live_handles--;
   delete m;
   return GX_OK;
 }
@@ -1025,6 +1089,7 @@ extern "C" int gx_comm_init(gx_ctx* ctx, const void* id128, int rank, int world,
   gx_comm* m = new (std::nothrow) gx_comm();
   if (!m) return fail(GX_ERR_OOM, "gx_comm_init: host allocation failed");
   m->ctx = ctx;
+  ctx->live_handles++;
   m->rank = rank;
   m->world = world;
   m->lib = open_rccl();

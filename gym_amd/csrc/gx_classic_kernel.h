@@ -92,44 +92,6 @@ __device__ __forceinline__ void store_flags_nt(uint8_t* base, uint64_t group, co
   }
 }
 
-// ------------------------------------------------- per-thread statistics ---
-// Integer-valued returns (every env but MountainCarContinuous and Pendulum)
-// accumulate in integer registers, branch-free.
-template <class EpRet>
-struct ThreadStats;
-
-template <>
-struct ThreadStats<int32_t> {
-  int32_t episodes = 0, sum_length = 0;
-  long long sum_return = 0, sum_return_sq = 0;
-  int32_t min_return = 0x7FFFFFFF, max_return = (int32_t)0x80000000;
-  __device__ __forceinline__ void add(bool d, int32_t ret, int32_t len) {
-    episodes += d ? 1 : 0;
-    sum_length += d ? len : 0;
-    const int32_t r = d ? ret : 0;
-    sum_return += r;
-    sum_return_sq += (long long)r * r;
-    min_return = d && ret < min_return ? ret : min_return;
-    max_return = d && ret > max_return ? ret : max_return;
-  }
-  __device__ __forceinline__ StatAcc widen() const {
-    StatAcc a;
-    a.episodes = episodes; a.sum_return = (double)sum_return; a.sum_length = sum_length;
-    a.sum_return_sq = (double)sum_return_sq;
-    if (episodes) { a.min_return = (double)min_return; a.max_return = (double)max_return; }
-    return a;
-  }
-};
-
-template <>
-struct ThreadStats<double> {
-  StatAcc acc;
-  __device__ __forceinline__ void add(bool d, double ret, int32_t len) {
-    if (d) acc.add(ret, len);
-  }
-  __device__ __forceinline__ StatAcc widen() const { return acc; }
-};
-
 // Integer-valued returns in the kernels that sample their own actions (the fused rollouts and the
 // in-kernel-policy step): every lane keeps its record in LDS (field-major, so a wave's access to
 // one field is conflict-free) and adds to it with return-less LDS atomics when one of its envs
@@ -193,7 +155,11 @@ struct RegState<E, std::void_t<decltype(E::NR)>> {
 // CACHED (fused K-step rollouts with the random policy): the policy block of four ticks is kept
 // in registers, so the generator runs once every four steps; the single-step kernels draw
 // the block and use one word of it (16 registers per lane fewer, one more resident wave).
-template <class E, int MODE, int POLICY, bool FUSED, bool BOUNDED, bool CACHED = false>
+// ROWS (gx_vec_rollout_out): every step's reward / done / truncated go to the caller's per-step rows,
+// or nothing at all is handed back (skip_last).  A separate variant because the extra pointers cost
+// the plain kernels registers (the scalar file is full: they spill into vector registers) and with
+// them a resident wave.
+template <class E, int MODE, int POLICY, bool FUSED, bool BOUNDED, bool CACHED = false, bool ROWS = false>
 __global__ void __launch_bounds__(kClassicBlock, (FUSED && BOUNDED) ? GX_FUSED_MIN_WAVES : 1) classic_step_kernel(StepArgs a) {
   using Real = typename E::Real;
   using Act = typename E::Act;
@@ -297,6 +263,12 @@ __global__ void __launch_bounds__(kClassicBlock, (FUSED && BOUNDED) ? GX_FUSED_M
         }
         pending |= d ? (1u << j) : 0u;
       }
+      if (ROWS && a.out_reward) {  // every step's results of a rollout, row k (uniform branch)
+        const uint64_t row = (uint64_t)k * a.stride;
+        store_row_nt<Rew, W>(static_cast<Rew*>(a.out_reward) + row, q, reward);
+        store_flags_nt<W>(a.out_done + row, q, done);
+        if (a.out_truncated) store_flags_nt<W>(a.out_truncated + row, q, trunc);
+      }
       // Auto-reset, compacted: each lane resets one finished env per round, so a
       // wave runs the RNG max-per-lane times instead of once per env slot.
       if (autoreset) {
@@ -332,9 +304,11 @@ __global__ void __launch_bounds__(kClassicBlock, (FUSED && BOUNDED) ? GX_FUSED_M
       if (ep_length_row) store_row<int32_t, W>(ep_length_row, q, ep_len);
     }
     // write-only rows: streamed past the caches, which stay with the rows the next step re-reads
-    store_row_nt<Rew, W>(static_cast<Rew*>(a.reward), q, reward);
-    store_flags_nt<W>(a.done, q, done);
-    if (truncated_row) store_flags_nt<W>(truncated_row, q, trunc);
+    if (!ROWS || !a.skip_last) {
+      store_row_nt<Rew, W>(static_cast<Rew*>(a.reward), q, reward);
+      store_flags_nt<W>(a.done, q, done);
+      if (truncated_row) store_flags_nt<W>(truncated_row, q, trunc);
+    }
     if constexpr (E::kDerivedObs) {
       float o[W][E::NOBS];
 #pragma unroll
@@ -421,8 +395,17 @@ __global__ void __launch_bounds__(kClassicBlock) classic_sample_kernel(StepArgs 
 template <class E, int MODE, int POLICY>
 static void launch_step_variant(const StepArgs& a, bool fused, bool bounded, dim3 grid, hipStream_t stream) {
   if (E::kAlwaysBounded) bounded = true;
-  if (fused && bounded && POLICY == GX_POLICY_RANDOM && a.k_steps > 1) {
-    hipLaunchKernelGGL((classic_step_kernel<E, MODE, POLICY, true, true, POLICY == GX_POLICY_RANDOM>), grid, dim3(kClassicBlock), 0, stream, a);
+  constexpr bool kRandom = POLICY == GX_POLICY_RANDOM;
+  if (a.out_reward || a.skip_last) {  // the per-step-rows variants
+    if (fused && bounded) {
+      hipLaunchKernelGGL((classic_step_kernel<E, MODE, POLICY, true, true, kRandom, true>), grid, dim3(kClassicBlock), 0, stream, a);
+    } else if constexpr (E::kAlwaysBounded) {
+      hipLaunchKernelGGL((classic_step_kernel<E, MODE, POLICY, false, true, false, true>), grid, dim3(kClassicBlock), 0, stream, a);
+    } else {
+      hipLaunchKernelGGL((classic_step_kernel<E, MODE, POLICY, false, false, false, true>), grid, dim3(kClassicBlock), 0, stream, a);
+    }
+  } else if (fused && bounded && kRandom && a.k_steps > 1) {
+    hipLaunchKernelGGL((classic_step_kernel<E, MODE, POLICY, true, true, kRandom>), grid, dim3(kClassicBlock), 0, stream, a);
   } else if (fused && bounded) {
     hipLaunchKernelGGL((classic_step_kernel<E, MODE, POLICY, true, true>), grid, dim3(kClassicBlock), 0, stream, a);
   } else if constexpr (E::kAlwaysBounded) {

@@ -37,10 +37,20 @@ constexpr int kStatFields = 6;
 //   NextDouble() stand-in: u = w * 2^-32;   Next(n) stand-in: (w * n) >> 32
 // `tick` counts the Reset()/Step() calls made on the batch before the one that
 // consumes the draw, so no per-env RNG state is stored or moved.
-// Streams: 0 = Reset draws, 1 = draws made inside Step, 2 = random policy.
+// Streams: 0 = Reset draws, 1 = draws made inside Step, 2 = random policy,
+// 3 = the per-tick word of the table-driven envs.
 // The policy stream takes one draw per env per tick, so four consecutive ticks
 // share a block: tick t reads word t % 4 of the block whose counter holds
 // t / 4, and a fused K-step rollout runs the generator once every four steps.
+// The table-driven envs (FrozenLake, Taxi, CliffWalking, DummyEnv) are stepped
+// four envs per lane and spend most of a step's arithmetic on the generator, so
+// their word is shared the other way: stream 3, one block per four consecutive
+// global env indices, env e reading word e % 4 of the block whose counter holds
+// e / 4 -- one generator call per lane per step.  That word w gives the random
+// policy its action and a slippery env the one draw its Step needs: with
+// u = w * 2^-32 the action is floor(u * A) and the outcome is the next base-O
+// digit of the same number, floor(frac(u * A) * O) -- independent of the
+// action and uniform to 2^-32.
 // ---------------------------------------------------------------------------
 struct RngKey {
   uint32_t k0, k1;     // seed
@@ -95,6 +105,20 @@ __device__ __forceinline__ uint32_t policy_word(const Draws& d, uint64_t tick) {
   const uint32_t i = (uint32_t)tick & 3u;
   return i == 0 ? d.w[0] : (i == 1 ? d.w[1] : (i == 2 ? d.w[2] : d.w[3]));
 }
+// Table-driven envs: the block of the four envs 4g .. 4g+3 at a tick (stream 3).
+__device__ __forceinline__ Draws tabular_block(uint32_t seed_lo, uint32_t seed_hi, uint64_t tick, uint64_t env_group) {
+  return philox_block(make_key(seed_lo, seed_hi, tick), env_group, 3, 0);
+}
+__device__ __forceinline__ uint32_t tabular_word(uint32_t seed_lo, uint32_t seed_hi, uint64_t tick, uint64_t env) {
+  const Draws d = tabular_block(seed_lo, seed_hi, tick, env >> 2);
+  const uint32_t i = (uint32_t)env & 3u;
+  return i == 0 ? d.w[0] : (i == 1 ? d.w[1] : (i == 2 ? d.w[2] : d.w[3]));
+}
+// the outcome in [0, n_out) a table-driven env draws inside Step: the base-n_out digit that
+// follows the action digit of its word of the tick (see the stream list above)
+__device__ __forceinline__ int32_t word_outcome(uint32_t w, uint32_t n_act, uint32_t n_out) {
+  return (int32_t)(__umulhi(w, n_act * n_out) - n_out * __umulhi(w, n_act));
+}
 // the two ways a draw is consumed: NextDouble() and Next(n)
 __device__ __forceinline__ double word_uniform(uint32_t w) { return (double)w * 0x1.0p-32; }
 __device__ __forceinline__ int32_t word_below(uint32_t w, uint32_t n) { return (int32_t)__umulhi(w, n); }
@@ -139,6 +163,44 @@ struct StatAcc {
     min_return = ret < min_return ? ret : min_return;
     max_return = ret > max_return ? ret : max_return;
   }
+};
+
+// Per-thread accumulators in front of StatAcc.
+// Integer-valued returns (every env but MountainCarContinuous and Pendulum)
+// accumulate in integer registers, branch-free.
+template <class EpRet>
+struct ThreadStats;
+
+template <>
+struct ThreadStats<int32_t> {
+  int32_t episodes = 0, sum_length = 0;
+  long long sum_return = 0, sum_return_sq = 0;
+  int32_t min_return = 0x7FFFFFFF, max_return = (int32_t)0x80000000;
+  __device__ __forceinline__ void add(bool d, int32_t ret, int32_t len) {
+    episodes += d ? 1 : 0;
+    sum_length += d ? len : 0;
+    const int32_t r = d ? ret : 0;
+    sum_return += r;
+    sum_return_sq += (long long)r * r;
+    min_return = d && ret < min_return ? ret : min_return;
+    max_return = d && ret > max_return ? ret : max_return;
+  }
+  __device__ __forceinline__ StatAcc widen() const {
+    StatAcc a;
+    a.episodes = episodes; a.sum_return = (double)sum_return; a.sum_length = sum_length;
+    a.sum_return_sq = (double)sum_return_sq;
+    if (episodes) { a.min_return = (double)min_return; a.max_return = (double)max_return; }
+    return a;
+  }
+};
+
+template <>
+struct ThreadStats<double> {
+  StatAcc acc;
+  __device__ __forceinline__ void add(bool d, double ret, int32_t len) {
+    if (d) acc.add(ret, len);
+  }
+  __device__ __forceinline__ StatAcc widen() const { return acc; }
 };
 
 __device__ __forceinline__ double shfl_down_f64(double v, int delta) {
@@ -203,6 +265,11 @@ struct StepArgs {
   float* obs;              // derived observation rows, or nullptr
   const uint32_t* table;   // tabular envs: packed transition table
   uint32_t* error_flag;    // set non-zero by a kernel that meets an action the reference throws on
+  // per-step outputs of a K-step rollout (gx_vec_rollout_out, GX_OUT_ALL): row k holds step k's
+  // values; nullptr = not wanted
+  void* out_reward;        // [k_steps][stride] float or double
+  uint8_t* out_done;       // [k_steps][stride]
+  uint8_t* out_truncated;  // [k_steps][stride] or nullptr
   uint64_t num_envs;
   uint64_t stride;
   uint64_t action_stride;
@@ -212,6 +279,7 @@ struct StepArgs {
   uint32_t flags;          // gx_flags
   int32_t time_limit;      // 0 = none
   int32_t k_steps;         // 1 for a single step
+  int32_t skip_last;       // GX_OUT_NONE: the reward / done / truncated rows of the view are not written
   uint32_t reverse;        // sweep the batch back to front (alternates launch to launch)
   int32_t table_states, table_actions, table_outcomes;
   int32_t start_state;

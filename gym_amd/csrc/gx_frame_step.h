@@ -12,7 +12,8 @@
 
 namespace gx {
 
-template <class G, int POLICY>
+// ROWS: the variant behind gx_vec_rollout_out (per-step reward / done / truncated rows, or none)
+template <class G, int POLICY, bool ROWS = false>
 __global__ void __launch_bounds__(kBlock) frame_step_kernel(StepArgs a) {
   const bool autoreset = (a.flags & GX_AUTORESET) != 0;
   const bool record = (a.flags & GX_RECORD_STATS) != 0;
@@ -50,15 +51,23 @@ __global__ void __launch_bounds__(kBlock) frame_step_kernel(StepArgs a) {
         }
       }
       if (autoreset && done) G::reset(s, key, env);
+      if (ROWS && a.out_reward) {  // every step's results of a rollout, row k
+        const uint64_t at = (uint64_t)k * a.stride + i;
+        static_cast<float*>(a.out_reward)[at] = reward;
+        a.out_done[at] = done;
+        if (a.out_truncated) a.out_truncated[at] = trunc;
+      }
     }
     G::store(a, i, s);
     if (record) {
       static_cast<int32_t*>(a.ep_return)[i] = ep_ret;
       if (a.ep_length) a.ep_length[i] = ep_len;
     }
-    static_cast<float*>(a.reward)[i] = reward;
-    a.done[i] = done;
-    if (a.truncated) a.truncated[i] = trunc;
+    if (!ROWS || !a.skip_last) {
+      static_cast<float*>(a.reward)[i] = reward;
+      a.done[i] = done;
+      if (a.truncated) a.truncated[i] = trunc;
+    }
   }
   if (record) block_commit_stats(acc, a.stat_slots);
 }
@@ -81,7 +90,10 @@ __global__ void __launch_bounds__(kBlock) frame_sample_kernel(StepArgs a, int32_
 
 template <class G>
 hipError_t launch_frame_step(const StepArgs& a, int policy, dim3 grid, hipStream_t stream) {
-  if (policy == GX_POLICY_RANDOM) hipLaunchKernelGGL((frame_step_kernel<G, GX_POLICY_RANDOM>), grid, dim3(kBlock), 0, stream, a);
+  if (a.out_reward || a.skip_last) {
+    if (policy == GX_POLICY_RANDOM) hipLaunchKernelGGL((frame_step_kernel<G, GX_POLICY_RANDOM, true>), grid, dim3(kBlock), 0, stream, a);
+    else hipLaunchKernelGGL((frame_step_kernel<G, GX_POLICY_DEVICE_ACTIONS, true>), grid, dim3(kBlock), 0, stream, a);
+  } else if (policy == GX_POLICY_RANDOM) hipLaunchKernelGGL((frame_step_kernel<G, GX_POLICY_RANDOM>), grid, dim3(kBlock), 0, stream, a);
   else hipLaunchKernelGGL((frame_step_kernel<G, GX_POLICY_DEVICE_ACTIONS>), grid, dim3(kBlock), 0, stream, a);
   return hipGetLastError();
 }

@@ -34,6 +34,16 @@ __device__ __forceinline__ uint32_t pack4(const bool (&b)[4]) {
   return (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
 }
 
+// step k's results of a rollout into row k of the caller's per-step rows, when they are wanted
+__device__ __forceinline__ void store_step_rows(const StepArgs& a, int k, uint64_t q, const float (&reward)[4], const bool (&done)[4],
+                                                const bool (&trunc)[4]) {
+  if (!a.out_reward) return;
+  const uint64_t row = (uint64_t)k * a.stride;
+  store4f_nt(static_cast<float*>(a.out_reward) + row, q, reward);
+  __builtin_nontemporal_store(pack4(done), reinterpret_cast<uint32_t*>(a.out_done + row) + q);
+  if (a.out_truncated) __builtin_nontemporal_store(pack4(trunc), reinterpret_cast<uint32_t*>(a.out_truncated + row) + q);
+}
+
 // Reset state: FrozenLake 0 (Envs.FrozenLake.cs:47), CliffWalking 36
 // (Envs.CliffWalking.cs:31), Taxi `Next(500)` (Envs.Taxi.cs:20).
 __device__ __forceinline__ int32_t tabular_reset_state(int32_t start_state, const RngKey& key, uint64_t env) {
@@ -47,10 +57,16 @@ __device__ __forceinline__ int32_t tabular_reset_state(int32_t start_state, cons
   return (cell * 5 + pass) * 4 + dest;
 }
 
-template <int POLICY, bool LDS_TABLE>
+// SLIP: the table has three outcomes per (state, action) (the slippery extension).
+// MULTI: the form behind rollouts and gx_vec_rollout_out (per-step rows, or no rows at all); the
+// single-step form does not carry their pointers.
+// ALIGNED: the batch's first global env index is a multiple of four, so a lane's four envs share one
+// generator block; otherwise every env fetches its word from its own block (four calls in flight cost
+// twenty registers, hence a variant of its own).
+template <int POLICY, bool LDS_TABLE, bool SLIP, bool MULTI, bool ALIGNED>
 __global__ void __launch_bounds__(kTabularBlock) tabular_step_kernel(StepArgs a) {
   extern __shared__ uint32_t lds_table[];
-  const int A = a.table_actions, ncols = A + 1, O = a.table_outcomes;
+  const int A = a.table_actions, ncols = A + 1, O = SLIP ? 3 : 1;
   const int entries = a.table_states * ncols * O;
   const uint32_t* tab = a.table;
   if (LDS_TABLE) {
@@ -67,7 +83,7 @@ __global__ void __launch_bounds__(kTabularBlock) tabular_step_kernel(StepArgs a)
   const bool derive_returns = a.derive_returns != 0;
   int32_t* const state_row = a.state_int;
   int32_t* const steps_row = a.state_int + a.stride;
-  StatAcc acc;
+  ThreadStats<int32_t> acc;  // every reward of a table is an integer: branch-free integer accumulation
 
   const uint64_t nquads = (a.num_envs + 3) >> 2;
   for (uint64_t it = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; it < nquads; it += (uint64_t)gridDim.x * blockDim.x) {
@@ -87,19 +103,33 @@ __global__ void __launch_bounds__(kTabularBlock) tabular_step_kernel(StepArgs a)
     }
     float reward[4];
     bool done[4], trunc[4];
+    // the env's word of the tick gives the random policy its action and a slippery env its outcome
+    constexpr bool need_word = POLICY == GX_POLICY_RANDOM || SLIP;
+    const uint64_t env0 = a.env_index_base + q * 4;
     for (int k = 0; k < a.k_steps; k++) {
       const uint64_t tick = a.tick + (uint64_t)k;
       const RngKey key = make_key(a.seed_lo, a.seed_hi, tick);
       int32_t act[4];
       if (POLICY == GX_POLICY_DEVICE_ACTIONS)
         load4i(static_cast<const int32_t*>(a.actions) + (uint64_t)k * a.action_stride, q, act);
+      uint32_t word[4] = {0, 0, 0, 0};
+      if (need_word) {
+        if (ALIGNED) {
+          const Draws d = tabular_block(a.seed_lo, a.seed_hi, tick, env0 >> 2);
+#pragma unroll
+          for (int j = 0; j < 4; j++) word[j] = d.w[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; j++) word[j] = tabular_word(a.seed_lo, a.seed_hi, tick, env0 + j);
+        }
+      }
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        const uint64_t env = a.env_index_base + q * 4 + j;
-        if (POLICY == GX_POLICY_RANDOM) act[j] = word_below(policy_word(policy_block(a.seed_lo, a.seed_hi, tick, env), tick), A);
+        const uint64_t env = env0 + j;
+        const uint32_t w = word[j];
+        if (POLICY == GX_POLICY_RANDOM) act[j] = word_below(w, A);
         const int col = (uint32_t)act[j] < (uint32_t)A ? act[j] : A;
-        int o = 0;
-        if (O > 1 && col < A) o = philox_block(key, env, 1, 0).below(0, O);
+        const int o = (SLIP && col < A) ? word_outcome(w, A, O) : 0;
         // a state outside the table (only reachable through set_state) is clamped
         const int s_in = (uint32_t)st[j] < (uint32_t)a.table_states ? st[j] : 0;
         const uint32_t e = tab[(s_in * ncols + col) * O + o];
@@ -114,17 +144,16 @@ __global__ void __launch_bounds__(kTabularBlock) tabular_step_kernel(StepArgs a)
         if (record) {  // EnvWrapper.cs:46-55
           ep_ret[j] += (int32_t)reward[j];
           ep_len[j] += 1;
-          if (d) {
-            if (q * 4 + j < a.num_envs) acc.add((double)ep_ret[j], a.ep_length ? ep_len[j] : steps[j]);
-            ep_ret[j] = 0;
-            ep_len[j] = 0;
-          }
+          acc.add(d && q * 4 + j < a.num_envs, ep_ret[j], a.ep_length ? ep_len[j] : steps[j]);
+          ep_ret[j] = d ? 0 : ep_ret[j];
+          ep_len[j] = d ? 0 : ep_len[j];
         }
         if (autoreset && d) {
           st[j] = tabular_reset_state(a.start_state, key, env);
           steps[j] = 0;
         }
       }
+      if (MULTI) store_step_rows(a, k, q, reward, done, trunc);
     }
     store4i(state_row, q, st);
     store4i(steps_row, q, steps);
@@ -133,16 +162,18 @@ __global__ void __launch_bounds__(kTabularBlock) tabular_step_kernel(StepArgs a)
       if (a.ep_length) store4i(a.ep_length, q, ep_len);
     }
     // write-only rows stream past the caches
-    store4f_nt(static_cast<float*>(a.reward), q, reward);
-    __builtin_nontemporal_store(pack4(done), reinterpret_cast<uint32_t*>(a.done) + q);
-    if (a.truncated) __builtin_nontemporal_store(pack4(trunc), reinterpret_cast<uint32_t*>(a.truncated) + q);
+    if (!MULTI || !a.skip_last) {
+      store4f_nt(static_cast<float*>(a.reward), q, reward);
+      __builtin_nontemporal_store(pack4(done), reinterpret_cast<uint32_t*>(a.done) + q);
+      if (a.truncated) __builtin_nontemporal_store(pack4(trunc), reinterpret_cast<uint32_t*>(a.truncated) + q);
+    }
   }
-  if (record) block_commit_stats(acc, a.stat_slots);
+  if (record) block_commit_stats(acc.widen(), a.stat_slots);
 }
 
 // DummyEnv.cs:23-30: state += action; reward = state; done = state >= 10.
 template <int POLICY>
-__global__ void __launch_bounds__(kTabularBlock) dummy_step_kernel(StepArgs a) {
+__global__ void __launch_bounds__(kTabularBlock) dummy_step_kernel(StepArgs a) {  // a test fixture: one form serves all
   const bool autoreset = (a.flags & GX_AUTORESET) != 0;
   const bool record = (a.flags & GX_RECORD_STATS) != 0;
   int32_t* const state_row = a.state_int;
@@ -169,7 +200,7 @@ __global__ void __launch_bounds__(kTabularBlock) dummy_step_kernel(StepArgs a) {
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         if (POLICY == GX_POLICY_RANDOM)  // Discrete(3), DummyEnv.cs:14
-          act[j] = word_below(policy_word(policy_block(a.seed_lo, a.seed_hi, tick, a.env_index_base + q * 4 + j), tick), 3);
+          act[j] = word_below(tabular_word(a.seed_lo, a.seed_hi, tick, a.env_index_base + q * 4 + j), 3);
         st[j] += act[j];
         steps[j] += 1;
         reward[j] = (float)st[j];
@@ -192,6 +223,7 @@ __global__ void __launch_bounds__(kTabularBlock) dummy_step_kernel(StepArgs a) {
           steps[j] = 0;
         }
       }
+      store_step_rows(a, k, q, reward, done, trunc);
     }
     store4i(state_row, q, st);
     store4i(steps_row, q, steps);
@@ -200,9 +232,11 @@ __global__ void __launch_bounds__(kTabularBlock) dummy_step_kernel(StepArgs a) {
       if (a.ep_length) store4i(a.ep_length, q, ep_len);
     }
     // write-only rows stream past the caches
-    store4f_nt(static_cast<float*>(a.reward), q, reward);
-    __builtin_nontemporal_store(pack4(done), reinterpret_cast<uint32_t*>(a.done) + q);
-    if (a.truncated) __builtin_nontemporal_store(pack4(trunc), reinterpret_cast<uint32_t*>(a.truncated) + q);
+    if (!a.skip_last) {
+      store4f_nt(static_cast<float*>(a.reward), q, reward);
+      __builtin_nontemporal_store(pack4(done), reinterpret_cast<uint32_t*>(a.done) + q);
+      if (a.truncated) __builtin_nontemporal_store(pack4(trunc), reinterpret_cast<uint32_t*>(a.truncated) + q);
+    }
   }
   if (record) block_commit_stats(acc, a.stat_slots);
 }
@@ -221,7 +255,7 @@ __global__ void __launch_bounds__(kTabularBlock) tabular_reset_kernel(StepArgs a
 
 __global__ void __launch_bounds__(kTabularBlock) tabular_sample_kernel(StepArgs a, int32_t nact, int32_t* out) {
   for (uint64_t i = (uint64_t)blockIdx.x * kTabularBlock + threadIdx.x; i < a.num_envs; i += (uint64_t)gridDim.x * kTabularBlock)
-    out[i] = word_below(policy_word(policy_block(a.seed_lo, a.seed_hi, a.tick, a.env_index_base + i), a.tick), nact);
+    out[i] = word_below(tabular_word(a.seed_lo, a.seed_hi, a.tick, a.env_index_base + i), nact);
 }
 
 hipError_t launch_tabular_step(int env_id, const StepArgs& a, int policy, dim3 grid, int block, size_t lds_bytes, hipStream_t stream) {
@@ -232,14 +266,24 @@ hipError_t launch_tabular_step(int env_id, const StepArgs& a, int policy, dim3 g
       hipLaunchKernelGGL(dummy_step_kernel<GX_POLICY_DEVICE_ACTIONS>, grid, dim3(block), 0, stream, a);
     return hipGetLastError();
   }
-  const bool lds = lds_bytes > 0;
-  if (policy == GX_POLICY_RANDOM) {
-    if (lds) hipLaunchKernelGGL((tabular_step_kernel<GX_POLICY_RANDOM, true>), grid, dim3(block), lds_bytes, stream, a);
-    else hipLaunchKernelGGL((tabular_step_kernel<GX_POLICY_RANDOM, false>), grid, dim3(block), 0, stream, a);
-  } else {
-    if (lds) hipLaunchKernelGGL((tabular_step_kernel<GX_POLICY_DEVICE_ACTIONS, true>), grid, dim3(block), lds_bytes, stream, a);
-    else hipLaunchKernelGGL((tabular_step_kernel<GX_POLICY_DEVICE_ACTIONS, false>), grid, dim3(block), 0, stream, a);
-  }
+  const bool lds = lds_bytes > 0, slip = a.table_outcomes > 1;
+  const bool multi = a.k_steps > 1 || a.out_reward || a.skip_last;
+  if (a.table_outcomes != 1 && a.table_outcomes != 3) return hipErrorInvalidValue;
+  const bool aligned = (a.env_index_base & 3) == 0;
+#define GX_TAB_LAUNCH(P, L_, S, M)                                                                                     \
+  do {                                                                                                                 \
+    if (aligned) hipLaunchKernelGGL((tabular_step_kernel<P, L_, S, M, true>), grid, dim3(block), lds_bytes, stream, a); \
+    else hipLaunchKernelGGL((tabular_step_kernel<P, L_, S, M, false>), grid, dim3(block), lds_bytes, stream, a);        \
+  } while (0)
+#define GX_TAB_PICK_M(P, L_, S) do { if (multi) GX_TAB_LAUNCH(P, L_, S, true); else GX_TAB_LAUNCH(P, L_, S, false); } while (0)
+#define GX_TAB_PICK_S(P, L_) do { if (slip) GX_TAB_PICK_M(P, L_, true); else GX_TAB_PICK_M(P, L_, false); } while (0)
+#define GX_TAB_PICK_L(P) do { if (lds) GX_TAB_PICK_S(P, true); else GX_TAB_PICK_S(P, false); } while (0)
+  if (policy == GX_POLICY_RANDOM) GX_TAB_PICK_L(GX_POLICY_RANDOM);
+  else GX_TAB_PICK_L(GX_POLICY_DEVICE_ACTIONS);
+#undef GX_TAB_PICK_L
+#undef GX_TAB_PICK_S
+#undef GX_TAB_PICK_M
+#undef GX_TAB_LAUNCH
   return hipGetLastError();
 }
 

@@ -149,6 +149,14 @@ class DeviceBatch:
     def rollout(self, k_steps, policy=L.POLICY_RANDOM, d_actions_ptr=None, stream=None):
         L.check(L.load().gx_vec_rollout(self._h, k_steps, policy, C.c_void_p(d_actions_ptr or 0), C.c_void_p(stream or 0)))
 
+    def rollout_out(self, k_steps, out, policy=L.POLICY_RANDOM, d_actions_ptr=None, reward_rows=None, done_rows=None,
+                    truncated_rows=None, stream=None):
+        """K fused steps; out = L.OUT_ALL writes every step's reward / done / truncated into the caller's device
+        rows [k_steps][stride] (device addresses), L.OUT_NONE writes none, L.OUT_LAST is rollout()."""
+        L.check(L.load().gx_vec_rollout_out(self._h, k_steps, policy, C.c_void_p(d_actions_ptr or 0), out,
+                                            C.c_void_p(reward_rows or 0), C.c_void_p(done_rows or 0),
+                                            C.c_void_p(truncated_rows or 0), C.c_void_p(stream or 0)))
+
     def sample_actions(self, tick, d_actions_ptr, stream=None):
         L.check(L.load().gx_vec_sample_actions(self._h, tick, C.c_void_p(d_actions_ptr), C.c_void_p(stream or 0)))
 

@@ -164,6 +164,8 @@ int gx_device_count(int* count);
 
 /* ---- context: one per GPU -------------------------------------------- */
 int gx_ctx_create(int device, gx_ctx** out);
+/* Fails with GX_ERR_INVALID (and frees nothing) while a batch or communicator created on the
+ * context is alive: gx_vec_destroy synchronises the context's streams, so destroy batches first. */
 int gx_ctx_destroy(gx_ctx* ctx);
 int gx_ctx_synchronize(gx_ctx* ctx);
 /* The HIP stream (hipStream_t) step kernels are launched on when the caller
@@ -186,7 +188,8 @@ int gx_vec_reset(gx_vec* vec);
  * Components of the SoA image (reals | ints), named after the reference's fields:
  *   CartPole   x, xDot, theta, thetaDot | steps          MountainCar(+Cont)  position, velocity | steps
  *   Pendulum   cos, sin, thetaDot | steps                Acrobot  cos1, sin1, cos2, sin2, thetaDot1, thetaDot2 | steps
- *   Acrobot+RK4 (f64) theta1, theta2, dtheta1, dtheta2 | steps
+ *   Acrobot+RK4 (f64) theta1, theta2, dtheta1, dtheta2 | steps   (set_state: finite values, |theta| <= 1024,
+ *                  else GX_ERR_INVALID; the next step wraps the angles to [-pi, pi])
  *   (the five above hold doubles under GX_MODE_FP64)
  *   tabular, Dummy   - | state, steps
  *   Pong (f64)     ballX, ballY, ballVelX, ballVelY, leftPaddleY, rightPaddleY | leftScore, rightScore, steps
@@ -211,6 +214,9 @@ int gx_vec_get_obs(gx_vec* vec, void* host_obs, size_t bytes);
  * ordered against the compute stream by events. */
 int gx_vec_step_async(gx_vec* vec, const void* h_actions, void* h_obs, void* h_reward, uint8_t* h_done,
                       uint8_t* h_truncated);
+/* Also waits for the stream of the batch's most recent step launch (a caller's own stream
+ * included) before it reads the invalid-action flag, so an error is reported by the wait that
+ * follows the offending step. */
 int gx_vec_wait(gx_vec* vec);
 
 /* VectorEnv.Step -- zero-copy path: actions already on the device, results
@@ -228,6 +234,17 @@ int gx_vec_device_view(gx_vec* vec, gx_view* out);
  * actions in the kernel; DEVICE_ACTIONS reads d_actions[K][stride].  The
  * reward/done/truncated arrays of the view hold the last step's values. */
 int gx_vec_rollout(gx_vec* vec, int k_steps, int policy, const void* d_actions, void* stream);
+
+/* The same with a choice of what the rollout hands back (VectorEnv.Step returns every step's
+ * tuple, VectorEnv.cs:28-34): GX_OUT_LAST as gx_vec_rollout; GX_OUT_ALL additionally writes every
+ * step's reward, done and (with a time limit, optional) truncated flag into caller-owned device
+ * rows, row k = step k: d_reward_rows [k_steps][stride] float or double (gx_info.reward_dtype),
+ * d_done_rows / d_truncated_rows uint8 [k_steps][stride], 16-byte aligned (5 or 9 more bytes per
+ * env-step; the state still never leaves registers); GX_OUT_NONE writes no reward/done rows at
+ * all (statistics only), the rows of the view keep their old contents. */
+typedef enum gx_rollout_out { GX_OUT_LAST = 0, GX_OUT_ALL = 1, GX_OUT_NONE = 2 } gx_rollout_out;
+int gx_vec_rollout_out(gx_vec* vec, int k_steps, int policy, const void* d_actions, int out, void* d_reward_rows,
+                       uint8_t* d_done_rows, uint8_t* d_truncated_rows, void* stream);
 
 /* Draws of the random policy for one tick, written to a device array
  * (int32 or float [num_envs]); for harnesses that replay the same actions

@@ -74,6 +74,12 @@ uint32_t gxo_rng_u32(uint64_t seed, uint64_t env_index, uint64_t tick, uint32_t 
     draw = (uint32_t)(tick & 3u);
     tick >>= 2;
   }
+  if (stream == 3) {
+    /* the per-tick word of the table-driven envs (FrozenLake, Taxi, CliffWalking, DummyEnv): four
+     * consecutive envs share a block (counter env / 4), env e reading word e % 4 */
+    draw = (uint32_t)(env_index & 3u);
+    env_index >>= 2;
+  }
   ctr[0] = (uint32_t)env_index;
   ctr[1] = (uint32_t)(env_index >> 32);
   ctr[2] = (uint32_t)tick;
@@ -798,8 +804,13 @@ static int grid_step(env_obj* e, const void* action, const rng_ctx* r, double* r
   if (g->slippery && a >= 0 && a <= 3) {
     /* EXTENSION (upstream is_slippery; the reference declares _rng and never
      * uses it, Envs.FrozenLake.cs:16): the executed action is a-1, a or a+1
-     * (mod 4) with probability 1/3 each. */
-    int k = gxo_rng_below(r->seed, r->env_index, r->tick, 1, 0, 3);
+     * (mod 4) with probability 1/3 each.  The outcome is drawn from the env's
+     * word w of the tick (stream 3): with u = w / 2^32, Discrete(4).Sample() of that tick
+     * is floor(4u) and the outcome is the next base-3 digit, floor(frac(4u) * 3)
+     * = floor(12u) - 3 floor(4u): one generator call serves both, the two are
+     * independent, and the outcome does not depend on the action passed in. */
+    uint64_t w = gxo_rng_u32(r->seed, r->env_index, r->tick, 3, 0);
+    int k = (int)((w * 12u) >> 32) - 3 * (int)((w * 4u) >> 32);
     a = (a + 3 + k) & 3;
   }
   int row = c->state / g->ncol;
@@ -1775,7 +1786,8 @@ static int vec_step_impl(gxo_vec* v, const void* actions, int random_policy, voi
           break;
         default: {
           static const int nact[GXO_NUM_ENVS] = {2, 3, 0, 0, 3, 4, 6, 4, 4, 3, 4, 6};
-          ai = gxo_rng_below(r.seed, r.env_index, r.tick, 2, 0, nact[v->env_id]);
+          const int tabular = v->env_id == GXO_FROZENLAKE || v->env_id == GXO_TAXI || v->env_id == GXO_CLIFFWALKING || v->env_id == GXO_DUMMY;
+          ai = gxo_rng_below(r.seed, r.env_index, r.tick, tabular ? 3 : 2, 0, nact[v->env_id]);
         }
       }
       if (v->action_is_float) {

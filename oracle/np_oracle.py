@@ -44,10 +44,19 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 
 def rng_u32(seed, env, tick, stream, draw):
     """word (draw & 3) of the Philox block (draw >> 2) of this (env, tick, stream); the policy
-    stream (2) has one draw per tick, word tick % 4 of the block of tick // 4"""
+    stream (2) has one draw per tick, word tick % 4 of the block of tick // 4; the per-tick word of
+    the table-driven envs (stream 3) is word env % 4 of the block of env // 4"""
     if stream == 2:
         draw, tick = tick & 3, tick >> 2
     env = np.asarray(env, np.uint64)
+    if stream == 3:
+        sel = (env & np.uint64(3)).astype(np.int64)
+        env = env >> np.uint64(2)
+        tick = int(tick)
+        c3 = np.uint64((3 << 24) | (((tick >> 32) & 0xFF) << 16))
+        o = philox4x32_10(env & M32, env >> np.uint64(32), np.full_like(env, tick & 0xFFFFFFFF),
+                          np.full_like(env, c3), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+        return np.choose(sel, o)
     tick = int(tick)
     c3 = np.uint64((stream << 24) | (((tick >> 32) & 0xFF) << 16) | ((draw >> 2) & 0xFFFF))
     o = philox4x32_10(env & M32, env >> np.uint64(32), np.full_like(env, tick & 0xFFFFFFFF),
@@ -369,9 +378,22 @@ def grid_move(state, action, nrow, ncol):
     return (row * ncol + col).astype(np.int32)
 
 
-def frozenlake_step(state, steps, action, rows=("SFFF", "FHFH", "FFFH", "HFFG")):
-    """Envs.FrozenLake.cs:52-69"""
+def slip_outcome(seed, env, tick, n_act=4, n_out=3):
+    """Extension (upstream is_slippery): the outcome drawn inside Step is the base-n_out digit that
+    follows the action digit of the env's word of the tick (stream 3): floor(w n_act n_out / 2^32) mod n_out."""
+    w = rng_u32(seed, env, tick, 3, 0)
+    hi = (w * np.uint64(n_act * n_out)) >> np.uint64(32)
+    return (hi % np.uint64(n_out)).astype(np.int32)
+
+
+def frozenlake_step(state, steps, action, rows=("SFFF", "FHFH", "FFFH", "HFFG"), slippery=None):
+    """Envs.FrozenLake.cs:52-69.  slippery = (seed, env, tick) turns on the is_slippery extension: an
+    action in 0..3 is executed as a-1, a or a+1 (mod 4) by slip_outcome."""
     nrow, ncol, goal, holes = parse_map(rows)
+    action = np.asarray(action)
+    if slippery is not None:
+        k = slip_outcome(*slippery)
+        action = np.where((action >= 0) & (action <= 3), (action + 3 + k) & 3, action)
     ns = grid_move(state, action, nrow, ncol)
     steps = steps + 1
     done = (ns == goal) | holes[ns] | (steps >= 100)

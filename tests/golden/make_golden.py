@@ -41,6 +41,10 @@ CASES = [
     ("cartpole", O.CARTPOLE, 2, {}), ("mountaincar", O.MOUNTAINCAR, 3, {}), ("mountaincar_cont", O.MOUNTAINCAR_CONT, None, {}),
     ("pendulum", O.PENDULUM, None, {}), ("acrobot", O.ACROBOT, 3, {}), ("frozenlake", O.FROZENLAKE, 4, {}),
     ("frozenlake_8x8", O.FROZENLAKE, 4, {"map_rows": ["SFFFFFFF", "FFFFFFFF", "FFFHFFFF", "FFFFFHFF", "FFFHFFFF", "FHHFFFHF", "FHFFHFHF", "FFFHFFFG"]}),
+    # extensions of this build (the reference's FrozenLake is deterministic, its Taxi a stub): pinned by the
+    # oracle's own definition only
+    ("frozenlake_8x8_slippery", O.FROZENLAKE, 4, {"flags": O.SLIPPERY, "map_rows": ["SFFFFFFF", "FFFFFFFF", "FFFHFFFF", "FFFFFHFF", "FFFHFFFF", "FHHFFFHF", "FHFFHFHF", "FFFHFFFG"]}),
+    ("taxi_full", O.TAXI, 6, {"flags": O.TAXI_FULL}),
     ("taxi", O.TAXI, 6, {}), ("cliffwalking", O.CLIFFWALKING, 4, {}), ("pong", O.PONG, 4, {}),
     ("breakout", O.BREAKOUT, 4, {}),
     ("spaceinvaders", O.SPACEINVADERS, 6, {}),
@@ -74,6 +78,8 @@ def main():
         out = dict(init=init, actions=actions, rewards=rewards, dones=dones, final=v.get_state_raw(), seed=np.int64(SEED))
         if kw.get("map_rows"):
             out["map_rows"] = np.array("/".join(kw["map_rows"]))
+        if kw.get("flags"):
+            out["flags"] = np.int64(kw["flags"])
         if frames:
             out["frame_index" if name in ("breakout", "spaceinvaders") else "frame_masks"] = np.stack(frames)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
@@ -106,6 +112,10 @@ def main_fp64():
 if __name__ == "__main__":
     if "--fp64-only" in sys.argv:
         main_fp64()
+        sys.exit(0)
+    if "--only" in sys.argv:  # python tests/golden/make_golden.py --only name [name ...]
+        CASES[:] = [c for c in CASES if c[0] in sys.argv]
+        main()
         sys.exit(0)
     main()
     main_fp64()

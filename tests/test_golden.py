@@ -14,8 +14,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 FILES = sorted(glob.glob(os.path.join(HERE, "golden", "*.npz")))
 ENV_OF = {"cartpole": "CARTPOLE", "mountaincar": "MOUNTAINCAR", "mountaincar_cont": "MOUNTAINCAR_CONT", "pendulum": "PENDULUM",
           "acrobot": "ACROBOT", "frozenlake": "FROZENLAKE", "frozenlake_8x8": "FROZENLAKE", "taxi": "TAXI",
+          "frozenlake_8x8_slippery": "FROZENLAKE", "taxi_full": "TAXI",
           "cliffwalking": "CLIFFWALKING", "pong": "PONG", "breakout": "BREAKOUT", "spaceinvaders": "SPACEINVADERS"}
-EXACT = {"frozenlake", "frozenlake_8x8", "taxi", "cliffwalking", "pong", "breakout", "spaceinvaders"}
+EXACT = {"frozenlake", "frozenlake_8x8", "taxi", "cliffwalking", "pong", "breakout", "spaceinvaders", "frozenlake_8x8_slippery", "taxi_full"}
 
 
 def load(path):
@@ -36,7 +37,7 @@ def palette_index(frames):
 
 
 def test_fixtures_present():
-    assert len(FILES) == 17
+    assert len(FILES) == 19
 
 
 @pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f)[:-4] for f in FILES])
@@ -45,7 +46,7 @@ def test_oracle_reproduces_golden(oracle, path):
     n = z["actions"].shape[1]
     fp64 = name.endswith("_fp64")
     v = oracle.OracleVec(getattr(oracle, ENV_OF[name[:-5] if fp64 else name]), n, seed=int(z["seed"]), map_rows=rows,
-                         flags=oracle.FP64 if fp64 else 0)
+                         flags=oracle.FP64 if fp64 else (int(z["flags"]) if "flags" in z.files else 0))
     v.reset()
     assert np.array_equal(v.get_state_raw(), z["init"])
     frames = []
@@ -71,7 +72,8 @@ def test_gpu_reproduces_golden(path):
     n = z["actions"].shape[1]
     if name.endswith("_fp64"):
         return gpu_fp64_golden(name, z, n)
-    g = DeviceBatch(ctx(), getattr(L, "ENV_" + ENV_OF[name]), n, seed=int(z["seed"]), map_rows=rows)
+    g = DeviceBatch(ctx(), getattr(L, "ENV_" + ENV_OF[name]), n, seed=int(z["seed"]), map_rows=rows,
+                    flags=int(z["flags"]) if "flags" in z.files else 0)
     g.reset()
     assert np.array_equal(g.get_state_raw(), z["init"])  # Reset() draws are integer / one-rounding work: exact
     frames = []

@@ -144,6 +144,29 @@ def test_grid_worlds_bitwise(oracle):
         assert np.array_equal(v.get_obs(), st) and np.array_equal(rew, rew2) and np.array_equal(done.astype(bool), done2)
 
 
+def test_frozenlake_slippery_extension_bitwise(oracle):
+    """is_slippery (an extension; the reference is deterministic): both restatements take the outcome from
+    the env's word of the tick, the digit after the action digit"""
+    rows8 = ["SFFFFFFF", "FFFFFFFF", "FFFHFFFF", "FFFFFHFF", "FFFHFFFF", "FHHFFFHF", "FHFFHFHF", "FFFHFFFG"]
+    n = 4000
+    rng = np.random.default_rng(8)
+    v = oracle.OracleVec(oracle.FROZENLAKE, n, seed=SEED, flags=oracle.SLIPPERY, map_rows=rows8)
+    v.reset()
+    env = np.arange(n, dtype=np.uint64)
+    st = np.zeros(n, np.int32); steps = np.zeros(n, np.int32)
+    counts = np.zeros((4, 3), np.int64)
+    for t in range(80):
+        a = rng.integers(-1, 6, n).astype(np.int32)
+        rew, done, _ = v.step(a)
+        st, steps, rew2, done2 = NP.frozenlake_step(st, steps, a, rows=rows8, slippery=(SEED, env, t + 1))
+        assert np.array_equal(v.get_obs(), st) and np.array_equal(rew, rew2) and np.array_equal(done.astype(bool), done2)
+        # the outcome is independent of the action the random policy would draw from the same word
+        k = NP.slip_outcome(SEED, env, t + 1)
+        pa = NP.rng_below(SEED, env, t + 1, 3, 0, 4)
+        np.add.at(counts, (pa, k), 1)
+    assert counts.min() > 0.9 * counts.sum() / 12 and counts.max() < 1.1 * counts.sum() / 12
+
+
 def test_pong_bitwise(oracle):
     n = 300
     v = oracle.OracleVec(oracle.PONG, n, seed=SEED)
