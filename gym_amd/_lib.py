@@ -52,6 +52,20 @@ class GxStats(C.Structure):
     ]
 
 
+class GxRows(C.Structure):
+    """gx_rows: caller-owned device rows for gx_rows_step, the entry point that allocates nothing"""
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("env_id", C.c_int32), ("num_envs", C.c_uint64), ("stride", C.c_uint64),
+        ("seed", C.c_uint64), ("env_index_base", C.c_uint64), ("tick", C.c_uint64), ("mode", C.c_int32),
+        ("state_bounded", C.c_int32), ("state_real", C.c_void_p), ("steps", C.c_void_p), ("ep_return", C.c_void_p),
+        ("actions", C.c_void_p), ("reward", C.c_void_p), ("done", C.c_void_p), ("stats", C.c_void_p),
+        ("error", C.c_void_p),
+    ]
+
+
+ROWS_MAX_ENVS = 1 << 24
+
+
 class GymxError(RuntimeError):
     def __init__(self, code, message):
         super().__init__("gymx error %d: %s" % (code, message))
@@ -85,6 +99,7 @@ SIGNATURES = {
     "gx_vec_sample_actions": (_i, [_vp, _u64, _vp, _vp]),
     "gx_vec_tick": (_i, [_vp, C.POINTER(_u64)]),
     "gx_vec_stats": (_i, [_vp, C.POINTER(GxStats)]),
+    "gx_rows_step": (_i, [_vp, C.POINTER(GxRows), _i, _vp]),
     "gx_comm_unique_id": (_i, [_vp]),
     "gx_comm_init": (_i, [_vp, _vp, _i, _i, C.POINTER(_vp)]),
     "gx_comm_destroy": (_i, [_vp]),

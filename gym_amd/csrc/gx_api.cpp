@@ -50,6 +50,7 @@ struct gx_ctx {
   hipStream_t copy = nullptr;
   hipEvent_t ev_in = nullptr;
   hipEvent_t ev_out = nullptr;
+  char* scratch = nullptr;  // this device's copy of g_rows_scratch (gx_rows_step)
   int live_handles = 0;     // batches and communicators created on this context and not yet destroyed
 };
 
@@ -135,6 +136,19 @@ extern "C" int gx_device_count(int* count) {
   return GX_OK;
 }
 
+// ------------------------------------------------- gx_rows_step's scratch ---
+// gx_rows_step allocates nothing: the per-wave statistics records of its step kernel, the
+// reduced record and the invalid-action flag live in this array, of which every GPU the library
+// runs on holds its own copy at its own address until the process ends.  Host code never uses
+// the array's name as an address: gx_ctx_create asks the runtime for this device's copy once
+// and keeps the pointer in the context.
+constexpr uint64_t kRowsMaxEnvs = GX_ROWS_MAX_ENVS;
+constexpr int kRowsMaxSlots = 32768;  // waves of the largest grid: 2^24 envs / 4 per lane / 64 lanes / 2 trips
+constexpr size_t kRowsResultOffset = (size_t)kRowsMaxSlots * sizeof(StatSlot);
+constexpr size_t kRowsErrorOffset = kRowsResultOffset + sizeof(StatSlot);
+constexpr size_t kRowsScratchBytes = kRowsErrorOffset + 256;  // 2 MiB + 320 bytes
+static __device__ __align__(256) unsigned char g_rows_scratch[kRowsScratchBytes];
+
 // ------------------------------------------------------------------ context ---
 extern "C" int gx_ctx_create(int device, gx_ctx** out) {
   if (!out) return fail(GX_ERR_INVALID, "gx_ctx_create: null out pointer");
@@ -160,6 +174,14 @@ extern "C" int gx_ctx_create(int device, gx_ctx** out) {
     gx_ctx_destroy(c);
     return fail(GX_ERR_HIP, "gx_ctx_create: stream/event creation failed: %s", hipGetErrorString(e));
   }
+  // this device is current: the address returned is the one of its copy of the array
+  void* scratch = nullptr;
+  e = hipGetSymbolAddress(&scratch, HIP_SYMBOL(g_rows_scratch));
+  if (e != hipSuccess || !scratch) {
+    gx_ctx_destroy(c);
+    return fail(GX_ERR_HIP, "gx_ctx_create: hipGetSymbolAddress(g_rows_scratch) failed: %s", hipGetErrorString(e));
+  }
+  c->scratch = static_cast<char*>(scratch);
   *out = c;
   return GX_OK;
 }
@@ -1031,6 +1053,76 @@ extern "C" int gx_vec_stats(gx_vec* v, gx_stats* out) {
   out->sum_return_sq = v->h_stat->sum_return_sq;
   out->min_return = v->h_stat->min_return;
   out->max_return = v->h_stat->max_return;
+  return GX_OK;
+}
+
+// ------------------------------------------------- the no-allocation entry ---
+extern "C" int gx_rows_step(gx_ctx* c, const gx_rows* r, int k_steps, void* stream_) {
+  if (!c || !r) return fail(GX_ERR_INVALID, "gx_rows_step: null argument");
+  if (r->struct_size != sizeof(gx_rows)) return fail(GX_ERR_INVALID, "gx_rows_step: gx_rows.struct_size is %u, expected %zu", r->struct_size, sizeof(gx_rows));
+  if (r->env_id < GX_ENV_CARTPOLE || r->env_id > GX_ENV_ACROBOT) return fail(GX_ERR_UNSUPPORTED, "gx_rows_step: env id %d is not one of the five classic-control envs", r->env_id);
+  if (r->mode != GX_MODE_EXACT && r->mode != GX_MODE_FAST32) return fail(GX_ERR_UNSUPPORTED, "gx_rows_step: mode %d (binary32 modes only)", r->mode);
+  if (r->num_envs == 0) return fail(GX_ERR_INVALID, "gx_rows_step: num_envs must be positive");
+  if (r->num_envs > kRowsMaxEnvs)
+    return fail(GX_ERR_INVALID, "gx_rows_step: %llu envs exceed the %llu the library's fixed scratch array serves", (unsigned long long)r->num_envs, (unsigned long long)kRowsMaxEnvs);
+  if ((r->stride & 3) || r->stride < r->num_envs) return fail(GX_ERR_INVALID, "gx_rows_step: stride %llu must be a multiple of 4 and >= num_envs", (unsigned long long)r->stride);
+  if (k_steps <= 0) return fail(GX_ERR_INVALID, "gx_rows_step: k_steps must be positive");
+  const bool f64_return = r->env_id == GX_ENV_MOUNTAINCAR_CONT || r->env_id == GX_ENV_PENDULUM;
+  if (!r->state_real || !r->steps || !r->reward || !r->done || !r->stats) return fail(GX_ERR_INVALID, "gx_rows_step: null row pointer");
+  if (f64_return && !r->ep_return) return fail(GX_ERR_INVALID, "gx_rows_step: this env needs the ep_return row");
+  // the kernel that tolerates unbounded angles keeps the return row explicitly (Acrobot re-derives its
+  // angles with atan2 every step and has no such kernel)
+  if (!r->ep_return && !r->state_bounded && r->env_id != GX_ENV_ACROBOT)
+    return fail(GX_ERR_INVALID, "gx_rows_step: state_bounded = 0 needs an int32 ep_return row for this env");
+  const void* ptrs[] = {r->state_real, r->steps, r->ep_return, r->actions, r->reward, r->done, r->stats};
+  for (const void* p : ptrs)
+    if ((uintptr_t)p & 15) return fail(GX_ERR_INVALID, "gx_rows_step: row pointers must be 16-byte aligned");
+  if (!c->scratch) return fail(GX_ERR_HIP, "gx_rows_step: the context has no scratch address");
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t stream = stream_ ? (hipStream_t)stream_ : c->compute;
+
+  // the geometry gx_vec_create gives the same batch, within the slots the scratch array holds
+  const uint64_t groups = (r->num_envs + 3) / 4;
+  const uint64_t blocks = (groups + kClassicBlock - 1) / kClassicBlock;
+  const uint64_t cap = std::max<uint64_t>((blocks + 1) / 2, (uint64_t)c->num_cus * 4);
+  const dim3 grid((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min(blocks, cap), (uint64_t)kRowsMaxSlots)));
+  const int num_slots = std::max((int)grid.x * (kClassicBlock / 64), kBlock / 64);
+
+  StatSlot* slots = reinterpret_cast<StatSlot*>(c->scratch);
+  StatSlot* result = reinterpret_cast<StatSlot*>(c->scratch + kRowsResultOffset);
+  uint32_t* err = reinterpret_cast<uint32_t*>(c->scratch + kRowsErrorOffset);
+  // the array keeps the last call's contents: the records this call adds into start empty
+  HIP_TRY(launch_stats_init(slots, num_slots, stream));
+  HIP_TRY(hipMemsetAsync(err, 0, 4, stream));
+
+  StepArgs a{};
+  a.state_real = r->state_real;
+  a.state_int = r->steps;
+  a.actions = r->actions;
+  a.reward = r->reward;
+  a.done = r->done;
+  a.ep_return = r->ep_return;
+  a.stat_slots = slots;
+  a.error_flag = err;
+  a.num_envs = r->num_envs;
+  a.stride = r->stride;
+  a.action_stride = r->stride;
+  a.env_index_base = r->env_index_base;
+  a.tick = r->tick;
+  a.seed_lo = (uint32_t)r->seed;
+  a.seed_hi = (uint32_t)(r->seed >> 32);
+  a.flags = GX_AUTORESET | GX_RECORD_STATS;
+  a.k_steps = k_steps;
+  a.reverse = (uint32_t)(r->tick & 1u);
+  a.derive_returns = r->ep_return ? 0 : 1;
+  a.ret_per_step = r->env_id == GX_ENV_CARTPOLE ? 1 : -1;
+  const int policy = r->actions ? GX_POLICY_DEVICE_ACTIONS : GX_POLICY_RANDOM;
+  HIP_TRY(launch_classic_step(r->env_id, a, r->mode, policy, /*fused=*/true, /*bounded=*/r->state_bounded != 0, grid, stream));
+  HIP_TRY(launch_stats_reduce(slots, num_slots, result, stream));
+  // StatSlot begins with the six fields of gx_stats in the same order
+  static_assert(sizeof(gx_stats) == 48 && sizeof(gx_stats) <= sizeof(StatSlot), "gx_stats is the head of StatSlot");
+  HIP_TRY(hipMemcpyAsync(r->stats, result, sizeof(gx_stats), hipMemcpyDeviceToDevice, stream));
+  if (r->error) HIP_TRY(hipMemcpyAsync(r->error, err, 4, hipMemcpyDeviceToDevice, stream));
   return GX_OK;
 }
 

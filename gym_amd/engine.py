@@ -171,6 +171,16 @@ class DeviceBatch:
         return s
 
 
+def rows_step(ctx, env_id, num_envs, stride, seed, tick, state_real, steps, reward, done, stats, k_steps=1,
+              actions=None, ep_return=None, error=None, env_index_base=0, mode=L.MODE_EXACT, state_bounded=True,
+              stream=None):
+    """gx_rows_step: K fused steps + the statistics of the episodes they finish, on device rows the
+    caller owns (every pointer argument is a device address as an int); allocates nothing."""
+    r = L.GxRows(C.sizeof(L.GxRows), env_id, num_envs, stride, seed, env_index_base, tick, mode, 1 if state_bounded else 0,
+                 state_real, steps, ep_return, actions, reward, done, stats, error)
+    L.check(L.load().gx_rows_step(ctx._h, C.byref(r), k_steps, C.c_void_p(stream or 0)))
+
+
 class _DevicePtr:
     """Minimal __cuda_array_interface__ carrier so torch can wrap a library-owned row."""
 

@@ -258,6 +258,45 @@ int gx_vec_tick(const gx_vec* vec, uint64_t* tick);
  * gx_vec_get_obs and gx_vec_reset. */
 int gx_vec_stats(gx_vec* vec, gx_stats* out);
 
+/* ---- one entry point that allocates nothing ------------------------------ */
+/* No counterpart in the reference.  For callers that cannot allocate device memory around a
+ * step: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.
+ * gx_rows_step is gx_vec_rollout (k_steps = 1: gx_vec_step_device / gx_vec_step_random) followed
+ * by gx_vec_stats, on SoA rows the CALLER owns, for the five classic-control envs in binary32
+ * with GX_AUTORESET | GX_RECORD_STATS fused.  It calls no hipMalloc/hipFree or any other
+ * allocating routine and only enqueues on `stream`.  The per-wave statistics records its kernels
+ * need live in a fixed 2 MiB + 320 B array inside the library, one copy per GPU, held until the
+ * process ends; that bounds a call at GX_ROWS_MAX_ENVS envs (larger: GX_ERR_INVALID).  Every
+ * call on a GPU shares that GPU's array (cleared at the start of each call), so calls that overlap
+ * on one GPU -- two streams, two threads -- race: serialise them. */
+#define GX_ROWS_MAX_ENVS (1ull << 24)
+typedef struct gx_rows {
+  uint32_t struct_size;    /* sizeof(gx_rows) */
+  int32_t env_id;          /* GX_ENV_CARTPOLE .. GX_ENV_ACROBOT */
+  uint64_t num_envs;       /* 1 .. GX_ROWS_MAX_ENVS */
+  uint64_t stride;         /* elements between component rows: a multiple of 4, >= num_envs */
+  uint64_t seed;           /* as gx_desc */
+  uint64_t env_index_base; /* as gx_desc */
+  uint64_t tick;           /* the batch's tick before this call (gx_vec_tick); the caller adds k_steps */
+  int32_t mode;            /* GX_MODE_EXACT or GX_MODE_FAST32 */
+  int32_t state_bounded;   /* non-zero: every state is a Reset() draw or the result of an earlier step with
+                              auto-reset (what gx_vec_* tracks itself); 0 after states were written from outside */
+  float* state_real;       /* in/out [n_real][stride], the SoA image documented at gx_vec_get_state */
+  int32_t* steps;          /* in/out [stride], the per-env step counter */
+  void* ep_return;         /* in/out [stride], the open episode's return: double for MountainCarContinuous and
+                              Pendulum, int32 for the others.  May be NULL for CartPole, MountainCar (only with
+                              state_bounded != 0) and Acrobot: their open-episode return is then taken as the
+                              reward per step times the step counter, as gx_vec_* does until a gx_vec_set_state */
+  const void* actions;     /* in [k_steps][stride] int32 or float, or NULL: ActionSpace.Sample() in the kernel */
+  void* reward;            /* out [stride] float (double for MountainCarContinuous, Pendulum): last step's */
+  uint8_t* done;           /* out [stride]: last step's */
+  gx_stats* stats;         /* out, DEVICE memory: the episodes that finished during this call */
+  uint32_t* error;         /* out, device, may be NULL: set non-zero when Acrobot met an action outside {0,1,2} */
+} gx_rows;
+/* All pointers are device pointers, 16-byte aligned.  Padding elements [num_envs, stride) of the
+ * rows must be addressable; their values are ignored on input and unspecified on output. */
+int gx_rows_step(gx_ctx* ctx, const gx_rows* rows, int k_steps, void* stream);
+
 /* ---- multi-GPU: episode statistics only -------------------------------- */
 /* unique_id: 128 bytes, produced by rank 0 with gx_comm_unique_id and passed
  * to the other ranks by the host program. */
