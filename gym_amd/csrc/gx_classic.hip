@@ -231,10 +231,13 @@ struct Pendulum {
   static __device__ __forceinline__ Act sample(uint32_t w) { return box_sample(word_uniform(w), -2.0f, 2.0f); }
 };
 
+#ifndef GX_ACROBOT_W
+#define GX_ACROBOT_W 4
+#endif
 struct Acrobot {
   static constexpr int NS = 6;
   using Real = float;
-  static constexpr int W = 4;
+  static constexpr int W = GX_ACROBOT_W;
   static constexpr bool kDerivedObs = false;
   static constexpr int NOBS = 6;
   using Act = int32_t;
@@ -296,9 +299,26 @@ struct Acrobot {
                  2 * LINK_MASS_2 * LINK_LENGTH_1 * LINK_COM_POS_2 * dtheta2 * dtheta1 * sin2 +
                  (LINK_MASS_1 * LINK_COM_POS_1 + LINK_MASS_2 * LINK_LENGTH_1) * g * T::cos_minus_half_pi(theta1) +
                  phi2;
-    float ddtheta2 = divide<MODE>(u + divide<MODE>(d2, d1) * phi1 - LINK_MASS_2 * LINK_LENGTH_1 * LINK_COM_POS_2 * dtheta1 * dtheta1 * sin2 - phi2,
-                                  LINK_MASS_2 * LINK_COM_POS_2 * LINK_COM_POS_2 + LINK_MOI_2 - divide<MODE>(d2 * d2, d1));
-    float ddtheta1 = divide<MODE>(-(d2 * ddtheta2 + phi1), d1);
+    float ddtheta2, ddtheta1;
+#ifdef GX_OLD_DIV  // A/B builds only: the hardware divide sequence
+    constexpr bool kSharedReciprocals = false;
+#else
+    constexpr bool kSharedReciprocals = true;
+#endif
+    if (MODE == GX_MODE_EXACT && kSharedReciprocals) {
+      // Four IEEE quotients over two divisors, d1 = 3.5 + cos2 in [2.5, 4.5] and the denominator below in
+      // [0.57, 1.03]: each divisor's reciprocal is taken once in binary64 and every quotient is one product
+      // rounded to float -- the same bits as the divide (see math::div_by_rcp), half the instructions.
+      const double r_d1 = math::rcp_of_f32(d1);
+      const float den = LINK_MASS_2 * LINK_COM_POS_2 * LINK_COM_POS_2 + LINK_MOI_2 - math::div_by_rcp(d2 * d2, r_d1);
+      ddtheta2 = math::div_by_rcp(u + math::div_by_rcp(d2, r_d1) * phi1 - LINK_MASS_2 * LINK_LENGTH_1 * LINK_COM_POS_2 * dtheta1 * dtheta1 * sin2 - phi2,
+                                  math::rcp_of_f32(den));
+      ddtheta1 = math::div_by_rcp(-(d2 * ddtheta2 + phi1), r_d1);
+    } else {
+      ddtheta2 = divide<MODE>(u + divide<MODE>(d2, d1) * phi1 - LINK_MASS_2 * LINK_LENGTH_1 * LINK_COM_POS_2 * dtheta1 * dtheta1 * sin2 - phi2,
+                              LINK_MASS_2 * LINK_COM_POS_2 * LINK_COM_POS_2 + LINK_MOI_2 - divide<MODE>(d2 * d2, d1));
+      ddtheta1 = divide<MODE>(-(d2 * ddtheta2 + phi1), d1);
+    }
 
     dtheta1 += dt * ddtheta1;
     dtheta2 += dt * ddtheta2;

@@ -232,15 +232,16 @@ __global__ void __launch_bounds__(kClassicBlock, (FUSED && BOUNDED) ? GX_FUSED_M
         for (int j = 0; j < W; j++) policy[CACHED ? j : 0] = policy_block(a.seed_lo, a.seed_hi, tick, env0 + j);
       }
       uint32_t pending = 0;  // envs of this lane that finished in this step
+      bool bad_action = false;
 #pragma unroll
       for (int j = 0; j < W; j++) {
         if (POLICY == GX_POLICY_RANDOM) {
           if (!CACHED) policy[0] = policy_block(a.seed_lo, a.seed_hi, tick, env0 + j);
           act[j] = E::sample(policy_word(policy[CACHED ? j : 0], tick));
         }
-        if (E::kCheckAction && POLICY == GX_POLICY_DEVICE_ACTIONS) {
-          if (!E::action_valid(act[j]) && q * W + j < a.num_envs) atomicOr(a.error_flag, 1u);
-        }
+        // an action the reference throws on: noted per lane, reported once after the lane's envs (a branch
+        // per env would split their arithmetic into separate blocks)
+        if (E::kCheckAction && POLICY == GX_POLICY_DEVICE_ACTIONS) bad_action |= !E::action_valid(act[j]) && q * W + j < a.num_envs;
         bool d;
         E::template step<MODE, BOUNDED>(s[j], steps[j], act[j], reward[j], d);
         // Wrappers.TimeLimit.cs:26-31; its counter always equals the env's own
@@ -262,6 +263,9 @@ __global__ void __launch_bounds__(kClassicBlock, (FUSED && BOUNDED) ? GX_FUSED_M
           ep_len[j] = d ? 0 : ep_len[j];
         }
         pending |= d ? (1u << j) : 0u;
+      }
+      if (E::kCheckAction && POLICY == GX_POLICY_DEVICE_ACTIONS) {
+        if (bad_action) atomicOr(a.error_flag, 1u);
       }
       if (ROWS && a.out_reward) {  // every step's results of a rollout, row k (uniform branch)
         const uint64_t row = (uint64_t)k * a.stride;

@@ -280,6 +280,17 @@ GX_HD float div_by_total_mass(float x) {
   const float r = fmaf(-q, c, x);
   return fmaf(r, y, q);
 }
+// a / b in binary32, correctly rounded, without the hardware divide sequence, for dividends that share a
+// divisor: y = 1 / (double)b to within two units in the last place (rcp64), then (float)((double)a * y).
+// Why the second rounding is harmless: the double product is within 2^-51 (relative) of a / b, while the
+// quotient of two floats that is not itself representable stays at least 2^-48 away from every midpoint
+// between neighbouring floats (a - m b is a non-zero multiple of 2^-47 of its scale for a 25-bit midpoint
+// m); where the quotient is subnormal the same count gives 2^-174 against an error below 2^-177 for
+// divisors in [0.5, 8), and an exact midpoint needs a divisor that is a power of two, whose reciprocal is
+// exact.  b must be finite and non-zero (the Newton steps of rcp64 turn 1/0 into NaN): the callers'
+// divisors are bounded away from zero by construction.
+GX_HD double rcp_of_f32(float b) { return rcp64((double)b); }
+GX_HD float div_by_rcp(float a, double y) { return (float)((double)a * y); }
 GX_HD bool div_fast_range(float x) {
   const float a = fabsf(x);
   return a >= 0x1.0p-100f && a <= 0x1.0p100f;

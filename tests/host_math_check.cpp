@@ -5,6 +5,7 @@
 //                 [-pi/4, pi/4] against (float)sin((double)x), (float)cos(...)
 //   sincos_bounded: floats in [-16, 16] and their shifts by -pi/2 and +pi, the same way
 //   atan2_f64: random float pairs against (float)atan2((double)y, (double)x), and in binary64
+//   div_by_rcp: floats over every divisor of [2.5, 4.5] and [0.5, 1.25] against a / b
 //   div_by_total_mass: every `stride`-th float in [2^-100, 2^100], both signs,
 //                 against x / 1.1f
 // Prints the mismatch counts; exit status 0 when both are within bounds.
@@ -121,6 +122,34 @@ int main(int argc, char** argv) {
   }
   std::printf("atan2_f64: %llu float pairs, mismatches after rounding to float %llu, worst error %.3f ulp, special values %s\n", na, bad_a,
               worst_ulp, special_ok ? "ok" : "WRONG");
+  // ---- division through a binary64 reciprocal: every divisor of the two ranges the Acrobot step has
+  // (stepping through them), dividends of every magnitude including those with subnormal quotients, and
+  // the reciprocal pushed two units in the last place either way (the device's Newton reciprocal is not
+  // correctly rounded)
+  unsigned long long nq = 0, bad_q = 0;
+  {
+    uint64_t state = 0xA0761D6478BD642Full;
+    auto next32 = [&]() { state ^= state << 13; state ^= state >> 7; state ^= state << 17; return (uint32_t)(state >> 32); };
+    const float ranges[2][2] = {{2.5f, 4.5f}, {0.5f, 1.25f}};
+    for (int rg = 0; rg < 2; rg++)
+      for (uint32_t bb = to_bits(ranges[rg][0]); bb <= to_bits(ranges[rg][1]); bb += stride / 8 + 1) {
+        const float b = from_bits(bb);
+        const double y = 1.0 / (double)b;
+        const double ys[3] = {y, std::nextafter(std::nextafter(y, 0.0), 0.0), std::nextafter(std::nextafter(y, 9.0), 9.0)};
+        for (int k = 0; k < 6; k++) {
+          uint32_t ab = next32();
+          if (k == 4) ab = (ab & 0x807FFFFFu) | ((next32() % 4) << 23);  // tiny dividends: subnormal quotients
+          if ((ab & 0x7F800000u) == 0x7F800000u) continue;               // inf / NaN
+          const float a = k == 5 ? b * from_bits((ab & 0x007FFFFFu) | 0x3F800000u) : from_bits(ab);  // and exact quotients' neighbours
+          volatile float ref = a / b;
+          for (double yy : ys) {
+            nq++;
+            bad_q += to_bits(gx::math::div_by_rcp(a, yy)) != to_bits(ref);
+          }
+        }
+      }
+  }
+  std::printf("div_by_rcp: %llu quotients, mismatches %llu\n", nq, bad_q);
   // ---- division by 1.1f
   const float c11 = 1.0f + 0.1f;
   unsigned long long nd = 0, bad_d = 0;
@@ -135,6 +164,6 @@ int main(int argc, char** argv) {
     }
   std::printf("div_by_total_mass: %llu inputs, mismatches %llu\n", nd, bad_d);
   // one rounding-boundary event per ~2^28 trig calls is expected; the division must be exact
-  const bool ok = special_ok && worst_ulp <= 2.0 && bad_a * (1ull << 23) <= na + (1ull << 23) && worst < 1e-15 && worst_f < 3e-7 && worst_at < 6e-7 && bad_d == 0 && bad_b * (1ull << 24) <= nb + (1ull << 24) && bad_s * (1ull << 24) <= n + (1ull << 24) && bad_c * (1ull << 24) <= n + (1ull << 24);
+  const bool ok = special_ok && worst_ulp <= 2.0 && bad_a * (1ull << 23) <= na + (1ull << 23) && worst < 1e-15 && worst_f < 3e-7 && worst_at < 6e-7 && bad_d == 0 && bad_q == 0 && bad_b * (1ull << 24) <= nb + (1ull << 24) && bad_s * (1ull << 24) <= n + (1ull << 24) && bad_c * (1ull << 24) <= n + (1ull << 24);
   return ok ? 0 : 1;
 }
