@@ -13,9 +13,9 @@ LIB_PATH = os.environ.get("GYMX_LIB") or os.path.join(_HERE, "lib", "libgymx.so"
 GX_OK, GX_ERR_INVALID, GX_ERR_HIP, GX_ERR_OOM, GX_ERR_UNSUPPORTED, GX_ERR_RCCL = range(6)
 
 (ENV_CARTPOLE, ENV_MOUNTAINCAR, ENV_MOUNTAINCAR_CONT, ENV_PENDULUM, ENV_ACROBOT, ENV_FROZENLAKE, ENV_TAXI,
- ENV_CLIFFWALKING, ENV_PONG, ENV_DUMMY, ENV_BREAKOUT, ENV_SPACEINVADERS) = range(12)
+ ENV_CLIFFWALKING, ENV_PONG, ENV_DUMMY, ENV_BREAKOUT, ENV_SPACEINVADERS, ENV_BLACKJACK) = range(13)
 MODE_EXACT, MODE_FAST32, MODE_FP64 = 0, 1, 2
-AUTORESET, RECORD_STATS, SLIPPERY, TAXI_FULL, ACROBOT_RK4 = 1, 2, 4, 8, 16
+AUTORESET, RECORD_STATS, SLIPPERY, TAXI_FULL, ACROBOT_RK4, BLACKJACK_FULL = 1, 2, 4, 8, 16, 64
 POLICY_DEVICE_ACTIONS, POLICY_RANDOM = 0, 1
 OUT_LAST, OUT_ALL, OUT_NONE = 0, 1, 2
 F32, F64, I32, U8 = range(4)

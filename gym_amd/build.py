@@ -14,7 +14,7 @@ OBJ = os.path.join(HERE, "lib", "obj")
 LIB = os.path.join(HERE, "lib", "libgymx.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-SOURCES = ["gx_api.cpp", "gx_classic.hip", "gx_classic64.hip", "gx_acrobot64.hip", "gx_tabular.hip", "gx_pong.hip", "gx_breakout.hip", "gx_invaders.hip",
+SOURCES = ["gx_api.cpp", "gx_classic.hip", "gx_classic64.hip", "gx_acrobot64.hip", "gx_tabular.hip", "gx_blackjack.hip", "gx_pong.hip", "gx_breakout.hip", "gx_invaders.hip",
            "gx_stats.hip", "gx_hostpath.hip"]
 # -ffp-contract=off: EXACT mode is operation-for-operation binary32; fused
 # multiply-adds are written out explicitly where they are wanted.

@@ -64,6 +64,7 @@ struct gx_vec {
   int block = 256;  // threads per workgroup of this batch's step kernels
   bool is_classic = false, is_tabular = false, is_frame = false, is_acrobot64 = false;  // is_frame: Pong, Breakout, SpaceInvaders
   bool is_classic64 = false;  // GX_MODE_FP64 on one of the five classic-control envs
+  bool is_blackjack = false;  // int-state env like the tabular ones (is_tabular is set too), with kernels of its own
   bool ep_return_f64 = false;
   // device memory
   void* d_real = nullptr;
@@ -417,6 +418,7 @@ void fill_info(gx_vec* v) {
       in.n_real = 13; in.real_dtype = GX_F64; in.n_int = 9; in.obs_dim = 210 * 160 * 3; in.obs_dtype = GX_U8;
       in.action_n = 6; in.obs_is_state = 0;
       break;
+    case GX_ENV_BLACKJACK: in.n_real = 0; in.n_int = 3; in.obs_dim = 1; in.obs_dtype = GX_I32; in.action_n = 2; break;  // Envs.Blackjack.cs:12-13
   }
   if (v->is_classic64) in.real_dtype = in.obs_dtype = GX_F64;  // the observation is the binary64 state image
   in.state_bytes = v->n * ((uint64_t)in.n_real * dtype_size(in.real_dtype) + (uint64_t)in.n_int * 4);
@@ -505,6 +507,7 @@ int launch_step(gx_vec* v, const void* d_actions, int k_steps, uint64_t action_s
   if (v->is_acrobot64) e = launch_acrobot64_step(a, policy, fused, v->grid, stream);
   else if (v->is_classic64) e = launch_classic64_step(v->desc.env_id, a, policy, fused, bounded, v->grid, stream);
   else if (v->is_classic) e = launch_classic_step(v->desc.env_id, a, v->desc.mode, policy, fused, bounded, v->grid, stream);
+  else if (v->is_blackjack) e = launch_blackjack_step(a, policy, v->grid, stream);
   else if (v->is_tabular) e = launch_tabular_step(v->desc.env_id, a, policy, v->grid, v->block, v->table_lds_bytes, stream);
   else {
     e = frame_step(v, a, policy, stream);
@@ -528,6 +531,7 @@ int launch_sample(gx_vec* v, uint64_t tick, void* d_out, hipStream_t stream) {
   if (v->is_acrobot64) e = launch_acrobot64_sample(a, d_out, grid, stream);
   else if (v->is_classic64) e = launch_classic64_sample(v->desc.env_id, a, d_out, grid, stream);
   else if (v->is_classic) e = launch_classic_sample(v->desc.env_id, a, d_out, grid, stream);
+  else if (v->is_blackjack) e = launch_blackjack_sample(a, d_out, grid, stream);
   else if (v->is_tabular) e = launch_tabular_sample(v->desc.env_id, a, d_out, grid, stream);
   else if (v->desc.env_id == GX_ENV_PONG) e = launch_pong_sample(a, d_out, grid, stream);
   else if (v->desc.env_id == GX_ENV_BREAKOUT) e = launch_breakout_sample(a, d_out, grid, stream);
@@ -577,7 +581,7 @@ extern "C" int gx_vec_create(gx_ctx* ctx, const gx_desc* desc, gx_vec** out) {
   if (desc->num_envs > (1ull << 31)) return fail(GX_ERR_UNSUPPORTED, "gx_vec_create: more than 2^31 envs per batch");
   if (desc->mode != GX_MODE_EXACT && desc->mode != GX_MODE_FAST32 && desc->mode != GX_MODE_FP64) return fail(GX_ERR_INVALID, "gx_vec_create: unknown mode %d", desc->mode);
   if (desc->time_limit < 0) return fail(GX_ERR_INVALID, "gx_vec_create: negative time_limit");
-  const uint32_t known = GX_AUTORESET | GX_RECORD_STATS | GX_SLIPPERY | GX_TAXI_FULL | GX_ACROBOT_RK4;
+  const uint32_t known = GX_AUTORESET | GX_RECORD_STATS | GX_SLIPPERY | GX_TAXI_FULL | GX_ACROBOT_RK4 | GX_BLACKJACK_FULL;
   if (desc->flags & ~known) return fail(GX_ERR_INVALID, "gx_vec_create: unknown flag bits 0x%x", desc->flags & ~known);
   HIP_TRY(hipSetDevice(ctx->device));
 
@@ -593,7 +597,8 @@ extern "C" int gx_vec_create(gx_ctx* ctx, const gx_desc* desc, gx_vec** out) {
   v->is_acrobot64 = env == GX_ENV_ACROBOT && (desc->flags & GX_ACROBOT_RK4);
   v->is_classic = env <= GX_ENV_ACROBOT;
   v->is_classic64 = v->is_classic && !v->is_acrobot64 && desc->mode == GX_MODE_FP64;
-  v->is_tabular = env == GX_ENV_FROZENLAKE || env == GX_ENV_TAXI || env == GX_ENV_CLIFFWALKING || env == GX_ENV_DUMMY;
+  v->is_blackjack = env == GX_ENV_BLACKJACK;
+  v->is_tabular = env == GX_ENV_FROZENLAKE || env == GX_ENV_TAXI || env == GX_ENV_CLIFFWALKING || env == GX_ENV_DUMMY || v->is_blackjack;
   v->is_frame = env == GX_ENV_PONG || env == GX_ENV_BREAKOUT || env == GX_ENV_SPACEINVADERS;
   v->envs_per_lane = (v->is_acrobot64 || v->is_classic64) ? 2 : (v->is_frame ? 1 : 4);
   v->stride = (v->n + 3) & ~3ull;  // rows stay 16-byte aligned for every element width
@@ -611,7 +616,7 @@ extern "C" int gx_vec_create(gx_ctx* ctx, const gx_desc* desc, gx_vec** out) {
   } while (0)
 
   std::vector<uint32_t> table;
-  if (v->is_tabular && env != GX_ENV_DUMMY) {
+  if (v->is_tabular && env != GX_ENV_DUMMY && !v->is_blackjack) {
     int rc = build_table(v, table);
     if (rc != GX_OK) { gx_vec_destroy(v); return rc; }
     VEC_TRY(hipMalloc((void**)&v->d_table, table.size() * 4));
@@ -669,7 +674,7 @@ extern "C" int gx_vec_create(gx_ctx* ctx, const gx_desc* desc, gx_vec** out) {
     uint64_t groups = (v->n + v->envs_per_lane - 1) / v->envs_per_lane;
     v->block = kBlock;
     if (v->is_classic) v->block = kClassicBlock;
-    if (v->is_tabular) {
+    if (v->is_tabular && !v->is_blackjack) {
       v->block = table.size() * 4 <= kSmallTableBytes ? kTabularBlockSmallTable : kTabularBlock;
       if (const char* s = std::getenv("GYMX_TABULAR_BLOCK")) {  // tuning aid: 64, 128 or 256
         const int b = std::atoi(s);
@@ -756,6 +761,7 @@ extern "C" int gx_vec_reset(gx_vec* v) {
   if (v->is_acrobot64) e = launch_acrobot64_reset(a, 0, v->grid, c->compute);
   else if (v->is_classic64) e = launch_classic64_reset(v->desc.env_id, a, v->grid, c->compute);
   else if (v->is_classic) e = launch_classic_reset(v->desc.env_id, a, v->grid, c->compute);
+  else if (v->is_blackjack) e = launch_blackjack_reset(a, v->grid, c->compute);
   else if (v->is_tabular) e = launch_tabular_reset(v->desc.env_id, a, v->grid, c->compute);
   else {
     e = frame_reset(v, a, c->compute);

@@ -31,6 +31,11 @@ hipError_t launch_tabular_step(int env_id, const StepArgs& a, int policy, dim3 g
 hipError_t launch_tabular_reset(int env_id, const StepArgs& a, dim3 grid, hipStream_t stream);
 hipError_t launch_tabular_sample(int env_id, const StepArgs& a, void* out, dim3 grid, hipStream_t stream);
 
+// Blackjack (gx_blackjack.hip); always launched with kBlock threads per workgroup
+hipError_t launch_blackjack_step(const StepArgs& a, int policy, dim3 grid, hipStream_t stream);
+hipError_t launch_blackjack_reset(const StepArgs& a, dim3 grid, hipStream_t stream);
+hipError_t launch_blackjack_sample(const StepArgs& a, void* out, dim3 grid, hipStream_t stream);
+
 // Pong (gx_pong.hip)
 hipError_t launch_pong_step(const StepArgs& a, int policy, dim3 grid, hipStream_t stream);
 hipError_t launch_pong_reset(const StepArgs& a, dim3 grid, hipStream_t stream);

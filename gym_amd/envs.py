@@ -26,8 +26,17 @@ class DeviceEnv(Env):
 
     ENV_ID = None
     ID = None
+    _instances = 0  # process-wide count of envs constructed without a seed
 
-    def __init__(self, seed=0, device=0, mode=L.MODE_EXACT, flags=0, map_rows=None):
+    def __init__(self, seed=None, device=0, mode=L.MODE_EXACT, flags=0, map_rows=None):
+        # The reference gives every env its own unseeded Random (Envs.CartPole.cs:19), so two envs
+        # built side by side differ.  Here an env built without a seed takes the next stream of
+        # seed 0 (its index keys the counter RNG); an explicit seed is deterministic: stream 0 of it.
+        self._stream = 0
+        if seed is None:
+            seed = 0
+            self._stream = DeviceEnv._instances
+            DeviceEnv._instances += 1
         self._seed = seed
         self._device = device
         self._mode = mode
@@ -41,7 +50,7 @@ class DeviceEnv(Env):
             from .engine import DeviceBatch
 
             self._batch = DeviceBatch(default_context(self._device), self.ENV_ID, 1, seed=self._seed, mode=self._mode,
-                                      flags=self._flags, map_rows=self._map_rows)
+                                      flags=self._flags, map_rows=self._map_rows, env_index_base=self._stream)
         return self._batch
 
     def batch_config(self):
@@ -61,6 +70,7 @@ class DeviceEnv(Env):
         """Extension: the reference's Seed is empty (Env.cs:33-36); here it re-keys the counter RNG."""
         if seed is not None:
             self._seed = int(seed)
+            self._stream = 0
             if self._batch is not None:
                 self._batch.close()
                 self._batch = None
@@ -187,6 +197,23 @@ class CliffWalking(_IntStateEnv):
         super().__init__(**kw)
         self.ActionSpace = Discrete(4)
         self.ObservationSpace = Discrete(48)
+
+
+class Blackjack(DeviceEnv):
+    """Envs.Blackjack.cs:10-48: Env<(int,int,bool), int>.  The reference's Step is a ten-step stub; `full=True`
+    plays upstream Blackjack-v1 (infinite deck, natural = False, sab = False), an extension."""
+    ENV_ID, ID = L.ENV_BLACKJACK, "Blackjack-v1"
+
+    def __init__(self, full=False, **kw):
+        kw["flags"] = kw.get("flags", 0) | (L.BLACKJACK_FULL if full else 0)
+        super().__init__(**kw)
+        self.ActionSpace = Discrete(2)  # 0: stick, 1: hit
+        self.ObservationSpace = Discrete(32 * 11 * 2)
+
+    def _state_of(self, obs, index=0):
+        # the device keeps the observation as the index of Discrete(32*11*2)
+        i = int(obs[index])
+        return (i // 22, (i // 2) % 11, bool(i & 1))
 
 
 class Pong(DeviceEnv):

@@ -31,8 +31,8 @@ class EnvRegistry:
 
 def RegisterAll():
     """GymnasiumRegistration.cs:8-30, restricted to the ids with a device kernel.  The
-    Box2D-backed, Blackjack and stub ids of the reference are
+    Box2D-backed and the Atari/MuJoCo stub ids of the reference are
     not registered: Make() on them fails as for any unknown id."""
     for cls in (_envs.CartPole, _envs.MountainCar, _envs.MountainCarContinuous, _envs.Acrobot, _envs.Pendulum,
-                _envs.FrozenLake, _envs.Taxi, _envs.CliffWalking, _envs.Pong, _envs.Breakout, _envs.SpaceInvaders):
+                _envs.FrozenLake, _envs.Taxi, _envs.CliffWalking, _envs.Blackjack, _envs.Pong, _envs.Breakout, _envs.SpaceInvaders):
         EnvRegistry.Register(cls.ID, cls)

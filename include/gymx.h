@@ -58,7 +58,8 @@ typedef enum gx_env_id {
   GX_ENV_DUMMY = 9,            /* DummyEnv.cs */
   GX_ENV_BREAKOUT = 10,        /* "Breakout-v4"              Envs.Breakout.cs */
   GX_ENV_SPACEINVADERS = 11,   /* "SpaceInvaders-v4"         Envs.SpaceInvaders.cs */
-  GX_ENV_COUNT = 12
+  GX_ENV_BLACKJACK = 12,       /* "Blackjack-v1"             Envs.Blackjack.cs */
+  GX_ENV_COUNT = 13
 } gx_env_id;
 
 /* Numeric mode of the continuous-control kernels. */
@@ -79,8 +80,10 @@ typedef enum gx_flags {
   GX_RECORD_STATS = 2u, /* fuse RecordEpisodeStatistics (EnvWrapper.cs:23-58) into the step */
   GX_SLIPPERY = 4u,     /* extension: upstream FrozenLake is_slippery (the reference is deterministic) */
   GX_TAXI_FULL = 8u,    /* extension: upstream Taxi-v3 transitions (the reference is a stub) */
-  GX_ACROBOT_RK4 = 16u  /* extension: upstream Acrobot, classical RK4 in binary64
+  GX_ACROBOT_RK4 = 16u, /* extension: upstream Acrobot, classical RK4 in binary64
                            (the reference integrates with semi-implicit Euler in binary32) */
+  GX_BLACKJACK_FULL = 64u /* extension: upstream Blackjack-v1 rules, infinite deck, natural = False, sab = False
+                           (the reference's Step is a ten-step stub, Envs.Blackjack.cs:34-39) */
 } gx_flags;
 
 typedef enum gx_policy {
@@ -192,6 +195,9 @@ int gx_vec_reset(gx_vec* vec);
  *                  else GX_ERR_INVALID; the next step wraps the angles to [-pi, pi])
  *   (the five above hold doubles under GX_MODE_FP64)
  *   tabular, Dummy   - | state, steps
+ *   Blackjack        - | (playerSum*11 + dealerCard)*2 + usableAce (the index of ObservationSpace Discrete(704),
+ *                  Envs.Blackjack.cs:13), dealer's face-down cards (raw sum | "an ace among them" << 8; 0 unless
+ *                  GX_BLACKJACK_FULL), steps
  *   Pong (f64)     ballX, ballY, ballVelX, ballVelY, leftPaddleY, rightPaddleY | leftScore, rightScore, steps
  *   Breakout (f64) ballX, ballY, ballVelX, ballVelY, paddleX | score, lives, ballStuck,
  *                  bricks[0..3] (bit row*18+col of word (row*18+col)/32 set = brick present), steps

@@ -24,6 +24,7 @@
 #include <stdexcept>
 #include <string>
 #include <utility>
+#include <tuple>
 #include <vector>
 
 #include "gymx.h"
@@ -142,7 +143,7 @@ struct BatchOptions {
   bool record_stats = false;   // RecordEpisodeStatistics fused, EnvWrapper.cs:23-58
   int time_limit = 0;          // TimeLimit maxSteps fused, Wrappers.TimeLimit.cs:8; 0 = none
   int mode = GX_MODE_EXACT;
-  uint32_t extension_flags = 0;  // GX_SLIPPERY, GX_TAXI_FULL, GX_ACROBOT_RK4
+  uint32_t extension_flags = 0;  // GX_SLIPPERY, GX_TAXI_FULL, GX_ACROBOT_RK4, GX_BLACKJACK_FULL
   std::string map_rows;        // FrozenLake rows joined by '/', "" = default
   uint64_t env_index_base = 0;
   int device = 0;
@@ -267,6 +268,14 @@ struct CliffWalking {  // Envs.CliffWalking.cs:10-77
   static Discrete ActionSpace() { return Discrete(4); }
   static Discrete ObservationSpace() { return Discrete(48); }
 };
+struct Blackjack {  // Envs.Blackjack.cs:10-48
+  static constexpr int kEnvId = GX_ENV_BLACKJACK;
+  static constexpr const char* kId = "Blackjack-v1";
+  using State = std::tuple<int, int, bool>;  // (playerSum, dealerCard, usableAce)
+  using Action = int;
+  static Discrete ActionSpace() { return Discrete(2); }               // 0: stick, 1: hit
+  static Discrete ObservationSpace() { return Discrete(32 * 11 * 2); }
+};
 struct DummyEnv {  // DummyEnv.cs:10-38
   static constexpr int kEnvId = GX_ENV_DUMMY;
   static constexpr const char* kId = "Dummy";
@@ -319,6 +328,14 @@ template <>
 struct StateOf<int> {
   using Elem = int32_t;
   static int get(const std::vector<int32_t>& obs, uint64_t, uint64_t i) { return obs[i]; }
+};
+template <>
+struct StateOf<std::tuple<int, int, bool>> {  // the device holds the index of Discrete(32*11*2)
+  using Elem = int32_t;
+  static std::tuple<int, int, bool> get(const std::vector<int32_t>& obs, uint64_t, uint64_t i) {
+    const int32_t v = obs[i];
+    return {v / 22, (v / 2) % 11, (v & 1) != 0};
+  }
 };
 template <>
 struct StateOf<std::vector<uint8_t>> {
@@ -533,7 +550,7 @@ struct GymnasiumRegistration {
   static void Add() { EnvRegistry::Register(E::kId, [] { return std::static_pointer_cast<void>(std::make_shared<DeviceEnv<E>>()); }); }
   static void RegisterAll() {
     Add<CartPole>(); Add<MountainCar>(); Add<MountainCarContinuous>(); Add<Acrobot>(); Add<Pendulum>(); Add<FrozenLake>();
-    Add<Taxi>(); Add<CliffWalking>(); Add<Pong>(); Add<Breakout>(); Add<SpaceInvaders>();
+    Add<Taxi>(); Add<CliffWalking>(); Add<Blackjack>(); Add<Pong>(); Add<Breakout>(); Add<SpaceInvaders>();
   }
 };
 

@@ -984,6 +984,110 @@ static void dummy_import(env_obj* e, const void* reals, const int32_t* ints) {
 }
 static const env_vtbl dummy_vt = {dummy_reset, dummy_step, dummy_export, dummy_import, sizeof(dummy_t)};
 
+/* --------------------------------------------------------------- Blackjack */
+/* Envs.Blackjack.cs: state (playerSum, dealerCard, usableAce), Discrete(2) actions (0 stick, 1 hit),
+ * ObservationSpace Discrete(32*11*2).  The state image holds the observation as that space's
+ * index, (playerSum*11 + dealerCard)*2 + usableAce, then the dealer's face-down cards (raw sum in
+ * bits 0..7, "one of them is an ace" in bit 8; 0 under the reference's rules, which never deal
+ * them), then the step counter. */
+typedef struct {
+  env_obj base;
+  int32_t player_sum, dealer_card, usable_ace;
+  int32_t hidden_sum, hidden_ace; /* EXTENSION only */
+  int32_t steps;
+  int full;
+} blackjack_t;
+
+/* the 13 ranks of an infinite deck: ace = 1, 2..10, and jack/queen/king count 10 */
+static inline int bj_card(int rank_index) { return rank_index + 1 < 10 ? rank_index + 1 : 10; }
+
+/* Envs.Blackjack.cs:21-30 */
+static void blackjack_reset(env_obj* e, const rng_ctx* r) {
+  blackjack_t* c = (blackjack_t*)e;
+  if (!c->full) {
+    c->player_sum = 12 + gxo_rng_below(r->seed, r->env_index, r->tick, 0, 0, 10);  /* Next(12, 22) */
+    c->dealer_card = 1 + gxo_rng_below(r->seed, r->env_index, r->tick, 0, 1, 10);  /* Next(1, 11) */
+    c->usable_ace = gxo_rng_below(r->seed, r->env_index, r->tick, 0, 2, 2) == 1;   /* Next(2) == 1 */
+    c->hidden_sum = 0;
+    c->hidden_ace = 0;
+  } else {
+    /* EXTENSION (upstream Blackjack-v1): the dealer's two cards, then the player's two */
+    int d0 = bj_card(gxo_rng_below(r->seed, r->env_index, r->tick, 0, 0, 13));
+    int d1 = bj_card(gxo_rng_below(r->seed, r->env_index, r->tick, 0, 1, 13));
+    int p0 = bj_card(gxo_rng_below(r->seed, r->env_index, r->tick, 0, 2, 13));
+    int p1 = bj_card(gxo_rng_below(r->seed, r->env_index, r->tick, 0, 3, 13));
+    c->dealer_card = d0;
+    c->hidden_sum = d1;
+    c->hidden_ace = d1 == 1;
+    int raw = p0 + p1;
+    c->usable_ace = (p0 == 1 || p1 == 1) && raw + 10 <= 21;
+    c->player_sum = raw + (c->usable_ace ? 10 : 0);
+  }
+  c->steps = 0;
+}
+
+/* Envs.Blackjack.cs:32-40 -- the reference is a stub: ten steps, then reward 1. */
+static int blackjack_step(env_obj* e, const void* action, const rng_ctx* r, double* reward, int* done) {
+  blackjack_t* c = (blackjack_t*)e;
+  int a = *(const int32_t*)action;
+  c->steps++;
+  if (!c->full) {
+    *done = c->steps >= 10;
+    *reward = *done ? 1.0 : 0.0;
+    return 0;
+  }
+  /* EXTENSION: upstream rules (natural = False, sab = False).  Any action other than 0 hits. */
+  if (a != 0) {
+    /* the card is the base-13 digit that follows the action digit of the env's word of the tick
+     * (stream 3): floor(26u) - 13 floor(2u) with u = w / 2^32, as the slippery outcome of FrozenLake */
+    uint64_t w = gxo_rng_u32(r->seed, r->env_index, r->tick, 3, 0);
+    int card = bj_card((int)((w * 26u) >> 32) - 13 * (int)((w * 2u) >> 32));
+    int raw = c->player_sum - (c->usable_ace ? 10 : 0) + card;
+    c->usable_ace = (c->usable_ace || card == 1) && raw + 10 <= 21;
+    c->player_sum = raw + (c->usable_ace ? 10 : 0);
+    *done = c->player_sum > 21;
+    *reward = *done ? -1.0 : 0.0;
+  } else {
+    /* the dealer draws to 17 or more (stream 1, draws 0, 1, ...), then the scores are compared */
+    int raw = c->dealer_card + c->hidden_sum;
+    int ace = c->dealer_card == 1 || c->hidden_ace;
+    uint32_t k = 0;
+    for (;;) {
+      int sum = raw + ((ace && raw + 10 <= 21) ? 10 : 0);
+      if (sum >= 17) break;
+      int card = bj_card(gxo_rng_below(r->seed, r->env_index, r->tick, 1, k++, 13));
+      raw += card;
+      ace = ace || card == 1;
+      c->hidden_sum += card;
+      c->hidden_ace = c->hidden_ace || card == 1;
+    }
+    int dealer = raw + ((ace && raw + 10 <= 21) ? 10 : 0);
+    int ps = c->player_sum > 21 ? 0 : c->player_sum, ds = dealer > 21 ? 0 : dealer;
+    *done = 1;
+    *reward = (double)((ps > ds) - (ps < ds));
+  }
+  return 0;
+}
+
+static void blackjack_export(const env_obj* e, void* reals, int32_t* ints) {
+  (void)reals;
+  const blackjack_t* c = (const blackjack_t*)e;
+  ints[0] = (c->player_sum * 11 + c->dealer_card) * 2 + c->usable_ace;
+  ints[1] = c->hidden_sum | (c->hidden_ace << 8);
+  ints[2] = c->steps;
+}
+static void blackjack_import(env_obj* e, const void* reals, const int32_t* ints) {
+  (void)reals;
+  blackjack_t* c = (blackjack_t*)e;
+  c->usable_ace = ints[0] & 1;
+  c->dealer_card = (ints[0] >> 1) % 11;
+  c->player_sum = (ints[0] >> 1) / 11;
+  c->hidden_sum = ints[1] & 0xFF;
+  c->hidden_ace = (ints[1] >> 8) & 1;
+  c->steps = ints[2];
+}
+static const env_vtbl blackjack_vt = {blackjack_reset, blackjack_step, blackjack_export, blackjack_import, sizeof(blackjack_t)};
+
 /* -------------------------------------------------------------------- Pong */
 #define SCREEN_WIDTH 160
 #define SCREEN_HEIGHT 210
@@ -1664,6 +1768,7 @@ gxo_vec* gxo_vec_create(int env_id, uint64_t num_envs, uint64_t seed, uint32_t f
     case GXO_PONG: vt = &pong_vt; v->n_real = 6; v->real_is_f64 = 1; v->n_int = 3; v->obs_dim = GXO_PONG_FRAME_BYTES; break;
     case GXO_BREAKOUT: vt = &breakout_vt; v->n_real = 5; v->real_is_f64 = 1; v->n_int = 8; v->obs_dim = GXO_PONG_FRAME_BYTES; break;
     case GXO_SPACEINVADERS: vt = &invaders_vt; v->n_real = 13; v->real_is_f64 = 1; v->n_int = 9; v->obs_dim = GXO_PONG_FRAME_BYTES; break;
+    case GXO_BLACKJACK: vt = &blackjack_vt; v->n_real = 0; v->n_int = 3; v->obs_dim = 1; break;
   }
   int classic64 = 0;
   if ((flags & GXO_FP64) && env_id <= GXO_ACROBOT && !(env_id == GXO_ACROBOT && (flags & GXO_ACROBOT_RK4))) {
@@ -1698,6 +1803,7 @@ gxo_vec* gxo_vec_create(int env_id, uint64_t num_envs, uint64_t seed, uint32_t f
     e->vt = vt;
     if (v->grid) ((grid_t*)e)->g = v->grid;
     if (env_id == GXO_TAXI) ((taxi_t*)e)->full = (flags & GXO_TAXI_FULL) != 0;
+    if (env_id == GXO_BLACKJACK) ((blackjack_t*)e)->full = (flags & GXO_BLACKJACK_FULL) != 0;
     if (classic64) ((classic64_t*)e)->n = v->n_real;
     v->envs[i] = e;
   }
@@ -1785,8 +1891,9 @@ static int vec_step_impl(gxo_vec* v, const void* actions, int random_policy, voi
           af = gxo_box_sample(u, -2.0f, 2.0f);
           break;
         default: {
-          static const int nact[GXO_NUM_ENVS] = {2, 3, 0, 0, 3, 4, 6, 4, 4, 3, 4, 6};
-          const int tabular = v->env_id == GXO_FROZENLAKE || v->env_id == GXO_TAXI || v->env_id == GXO_CLIFFWALKING || v->env_id == GXO_DUMMY;
+          static const int nact[GXO_NUM_ENVS] = {2, 3, 0, 0, 3, 4, 6, 4, 4, 3, 4, 6, 2};
+          const int tabular = v->env_id == GXO_FROZENLAKE || v->env_id == GXO_TAXI || v->env_id == GXO_CLIFFWALKING || v->env_id == GXO_DUMMY ||
+                              v->env_id == GXO_BLACKJACK;
           ai = gxo_rng_below(r.seed, r.env_index, r.tick, tabular ? 3 : 2, 0, nact[v->env_id]);
         }
       }

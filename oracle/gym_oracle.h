@@ -43,7 +43,8 @@ enum {
   GXO_DUMMY = 9,         /* DummyEnv.cs */
   GXO_BREAKOUT = 10,     /* Envs.Breakout.cs */
   GXO_SPACEINVADERS = 11, /* Envs.SpaceInvaders.cs */
-  GXO_NUM_ENVS = 12
+  GXO_BLACKJACK = 12,    /* Envs.Blackjack.cs */
+  GXO_NUM_ENVS = 13
 };
 
 /* Wrapper / engine flags. */
@@ -53,8 +54,9 @@ enum {
   GXO_SLIPPERY = 4u,      /* extension: upstream FrozenLake is_slippery */
   GXO_TAXI_FULL = 8u,     /* extension: upstream Taxi-v3 dynamics */
   GXO_ACROBOT_RK4 = 16u,  /* extension: upstream Acrobot (RK4, fp64) */
-  GXO_FP64 = 32u          /* extension: the five classic-control envs computed and stored in binary64
+  GXO_FP64 = 32u,         /* extension: the five classic-control envs computed and stored in binary64
                              (the engine's GX_MODE_FP64) */
+  GXO_BLACKJACK_FULL = 64u /* extension: upstream Blackjack-v1 rules (the reference is a ten-step stub) */
 };
 
 #define GXO_PONG_FRAME_BYTES (210 * 160 * 3)

@@ -422,6 +422,73 @@ def dummy_step(state, steps, action):
     return ns, steps + 1, ns.astype(f64), ns >= 10
 
 
+# --------------------------------------------------------------- Blackjack
+DECK = np.array([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 10, 10, 10], np.int32)  # ace, 2..10, jack, queen, king
+
+
+def blackjack_reset(seed, env, tick):
+    """Envs.Blackjack.cs:21-30: Next(12, 22), Next(1, 11), Next(2) == 1 -> (sum, dealer, usable)"""
+    return (12 + rng_below(seed, env, tick, 0, 0, 10), 1 + rng_below(seed, env, tick, 0, 1, 10),
+            (rng_below(seed, env, tick, 0, 2, 2) == 1).astype(np.int32))
+
+
+def blackjack_step(steps):
+    """Envs.Blackjack.cs:32-40 (a stub in the reference): the state stays, ten steps, then reward 1"""
+    steps = steps + 1
+    done = steps >= 10
+    return steps, np.where(done, 1.0, 0.0), done
+
+
+def _hand_value(hand):
+    """upstream sum_hand / usable_ace over a list of cards -> (value, usable)"""
+    raw = sum(hand)
+    usable = 1 in hand and raw + 10 <= 21
+    return (raw + 10 if usable else raw), int(usable)
+
+
+def blackjack_full_deal(seed, env, tick):
+    """Extension (upstream Blackjack-v1 reset): dealer's two cards, then the player's two, from
+    stream 0.  Returns per-env [dealer hand, player hand] as Python lists of cards."""
+    cards = [DECK[rng_below(seed, env, tick, 0, d, 13)] for d in range(4)]
+    n = len(np.atleast_1d(env))
+    return [[[int(cards[0][i]), int(cards[1][i])], [int(cards[2][i]), int(cards[3][i])]] for i in range(n)]
+
+
+def blackjack_full_step(hands, action, seed, env, tick):
+    """Extension: upstream step (natural = False, sab = False) on the hands of blackjack_full_deal,
+    updated in place; any non-zero action hits.  The hit card is the base-13 digit after the action
+    digit of the env's word of the tick (stream 3); the dealer's draws are stream 1, draws 0, 1, ..."""
+    env = np.atleast_1d(np.asarray(env, np.uint64))
+    w = rng_u32(seed, env, tick, 3, 0)
+    hit_rank = ((w * np.uint64(26)) >> np.uint64(32)) % np.uint64(13)
+    reward = np.zeros(len(env))
+    done = np.zeros(len(env), bool)
+    for i, (dealer, player) in enumerate(hands):
+        if action[i] != 0:
+            player.append(int(DECK[int(hit_rank[i])]))
+            if _hand_value(player)[0] > 21:
+                reward[i], done[i] = -1.0, True
+        else:
+            k = 0
+            while _hand_value(dealer)[0] < 17:
+                dealer.append(int(DECK[int(rng_below(seed, env[i:i + 1], tick, 1, k, 13)[0])]))
+                k += 1
+            p, d = _hand_value(player)[0], _hand_value(dealer)[0]
+            p, d = (0 if p > 21 else p), (0 if d > 21 else d)
+            reward[i], done[i] = float(p > d) - float(p < d), True
+    return reward, done
+
+
+def blackjack_image(hands, steps):
+    """hands -> the three int rows of the state image: observation index, face-down cards, steps"""
+    obs, hidden = [], []
+    for dealer, player in hands:
+        v, u = _hand_value(player)
+        obs.append((v * 11 + dealer[0]) * 2 + u)
+        hidden.append(sum(dealer[1:]) | (int(1 in dealer[1:]) << 8))
+    return np.array([obs, hidden, list(steps)], np.int32)
+
+
 # -------------------------------------------------------------------- Pong
 def pong_reset_ball(seed, env, tick, stream):
     """Envs.Pong.cs:159-165"""

@@ -13,8 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libgym_oracle.so")
 
 (CARTPOLE, MOUNTAINCAR, MOUNTAINCAR_CONT, PENDULUM, ACROBOT, FROZENLAKE, TAXI, CLIFFWALKING, PONG, DUMMY,
- BREAKOUT, SPACEINVADERS) = range(12)
-AUTORESET, RECORD_STATS, SLIPPERY, TAXI_FULL, ACROBOT_RK4, FP64 = 1, 2, 4, 8, 16, 32
+ BREAKOUT, SPACEINVADERS, BLACKJACK) = range(13)
+AUTORESET, RECORD_STATS, SLIPPERY, TAXI_FULL, ACROBOT_RK4, FP64, BLACKJACK_FULL = 1, 2, 4, 8, 16, 32, 64
 PONG_FRAME_BYTES = 210 * 160 * 3
 FLOAT_ACTION = {MOUNTAINCAR_CONT, PENDULUM}
 

@@ -67,6 +67,17 @@ static void reference_unit_tests() {
     auto v = si.Step(0);
     CHECK(v.reward >= 0 && v.info.at("lives") == 3 && v.info.at("aliens_remaining") == 55 && v.info.at("player_x") == 76.0);
   }
+  {  // Envs.Blackjack.cs:21-40: the state is a tuple that never changes; reward 1 at the tenth step
+    DeviceEnv<Blackjack> env;
+    CHECK(env.ActionSpace.N == 2 && env.ObservationSpace.N == 704);
+    auto s0 = env.Reset();
+    CHECK(std::get<0>(s0) >= 12 && std::get<0>(s0) <= 21 && std::get<1>(s0) >= 1 && std::get<1>(s0) <= 10);
+    StepResult<std::tuple<int, int, bool>> r{};
+    for (int i = 0; i < 10; i++) {
+      r = env.Step(i & 1);
+      CHECK(r.state == s0 && r.done == (i == 9) && r.reward == (i == 9 ? 1.0 : 0.0));
+    }
+  }
   {  // DummyEnvTests.cs:6-21
     DeviceEnv<DummyEnv> env;
     CHECK(env.Reset() == 0);
@@ -80,7 +91,7 @@ static void reference_unit_tests() {
 
 static void registry_and_spaces() {
   GymnasiumRegistration::RegisterAll();  // GymnasiumRegistration.cs:8-30
-  CHECK(EnvRegistry::List().size() == 11);
+  CHECK(EnvRegistry::List().size() == 12);
   auto env = EnvRegistry::Make<DeviceEnv<CartPole>>("CartPole-v1");
   CHECK(env->Reset().size() == 4);
   bool threw = false;

@@ -45,6 +45,10 @@ CASES = [
     # oracle's own definition only
     ("frozenlake_8x8_slippery", O.FROZENLAKE, 4, {"flags": O.SLIPPERY, "map_rows": ["SFFFFFFF", "FFFFFFFF", "FFFHFFFF", "FFFFFHFF", "FFFHFFFF", "FHHFFFHF", "FHFFHFHF", "FFFHFFFG"]}),
     ("taxi_full", O.TAXI, 6, {"flags": O.TAXI_FULL}),
+    # Blackjack with auto-reset, so that the 64 steps hold many games: the reference's ten-step stub, and
+    # upstream's rules (an extension, pinned by the oracle's own definition only)
+    ("blackjack", O.BLACKJACK, 2, {"flags": O.AUTORESET}),
+    ("blackjack_full", O.BLACKJACK, 2, {"flags": O.BLACKJACK_FULL | O.AUTORESET}),
     ("taxi", O.TAXI, 6, {}), ("cliffwalking", O.CLIFFWALKING, 4, {}), ("pong", O.PONG, 4, {}),
     ("breakout", O.BREAKOUT, 4, {}),
     ("spaceinvaders", O.SPACEINVADERS, 6, {}),

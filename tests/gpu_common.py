@@ -33,7 +33,7 @@ def ulp_mismatch(a, b):
 
 
 N_ACT = {L.ENV_CARTPOLE: 2, L.ENV_MOUNTAINCAR: 3, L.ENV_ACROBOT: 3, L.ENV_FROZENLAKE: 4, L.ENV_TAXI: 6,
-         L.ENV_CLIFFWALKING: 4, L.ENV_PONG: 4, L.ENV_DUMMY: 3, L.ENV_BREAKOUT: 4, L.ENV_SPACEINVADERS: 6}
+         L.ENV_CLIFFWALKING: 4, L.ENV_PONG: 4, L.ENV_DUMMY: 3, L.ENV_BREAKOUT: 4, L.ENV_SPACEINVADERS: 6, L.ENV_BLACKJACK: 2}
 
 
 def random_actions(rng, env_id, n, wide=False):

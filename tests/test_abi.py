@@ -38,15 +38,16 @@ def test_enum_values_in_sync(oracle):
                   ("ENV_ACROBOT", "GX_ENV_ACROBOT"), ("ENV_FROZENLAKE", "GX_ENV_FROZENLAKE"), ("ENV_TAXI", "GX_ENV_TAXI"),
                   ("ENV_CLIFFWALKING", "GX_ENV_CLIFFWALKING"), ("ENV_PONG", "GX_ENV_PONG"), ("ENV_DUMMY", "GX_ENV_DUMMY"),
                   ("ENV_BREAKOUT", "GX_ENV_BREAKOUT"), ("ENV_SPACEINVADERS", "GX_ENV_SPACEINVADERS"),
+                  ("ENV_BLACKJACK", "GX_ENV_BLACKJACK"), ("BLACKJACK_FULL", "GX_BLACKJACK_FULL"),
                   ("AUTORESET", "GX_AUTORESET"), ("RECORD_STATS", "GX_RECORD_STATS"), ("SLIPPERY", "GX_SLIPPERY"),
                   ("TAXI_FULL", "GX_TAXI_FULL"), ("ACROBOT_RK4", "GX_ACROBOT_RK4"), ("GX_ERR_INVALID", "GX_ERR_INVALID"),
                   ("GX_ERR_RCCL", "GX_ERR_RCCL"), ("POLICY_RANDOM", "GX_POLICY_RANDOM"), ("MODE_FAST32", "GX_MODE_FAST32")]:
         assert getattr(L, py) == enum(c), py
     # the oracle numbers envs and flags the same way
     for name in ("CARTPOLE", "MOUNTAINCAR", "MOUNTAINCAR_CONT", "PENDULUM", "ACROBOT", "FROZENLAKE", "TAXI",
-                 "CLIFFWALKING", "PONG", "DUMMY", "BREAKOUT", "SPACEINVADERS"):
+                 "CLIFFWALKING", "PONG", "DUMMY", "BREAKOUT", "SPACEINVADERS", "BLACKJACK"):
         assert getattr(oracle, name) == getattr(L, "ENV_" + name)
-    for name in ("AUTORESET", "RECORD_STATS", "SLIPPERY", "TAXI_FULL", "ACROBOT_RK4"):
+    for name in ("AUTORESET", "RECORD_STATS", "SLIPPERY", "TAXI_FULL", "ACROBOT_RK4", "BLACKJACK_FULL"):
         assert getattr(oracle, name) == getattr(L, name)
 
 

@@ -14,9 +14,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 FILES = sorted(glob.glob(os.path.join(HERE, "golden", "*.npz")))
 ENV_OF = {"cartpole": "CARTPOLE", "mountaincar": "MOUNTAINCAR", "mountaincar_cont": "MOUNTAINCAR_CONT", "pendulum": "PENDULUM",
           "acrobot": "ACROBOT", "frozenlake": "FROZENLAKE", "frozenlake_8x8": "FROZENLAKE", "taxi": "TAXI",
-          "frozenlake_8x8_slippery": "FROZENLAKE", "taxi_full": "TAXI",
+          "frozenlake_8x8_slippery": "FROZENLAKE", "taxi_full": "TAXI", "blackjack": "BLACKJACK", "blackjack_full": "BLACKJACK",
           "cliffwalking": "CLIFFWALKING", "pong": "PONG", "breakout": "BREAKOUT", "spaceinvaders": "SPACEINVADERS"}
-EXACT = {"frozenlake", "frozenlake_8x8", "taxi", "cliffwalking", "pong", "breakout", "spaceinvaders", "frozenlake_8x8_slippery", "taxi_full"}
+EXACT = {"frozenlake", "frozenlake_8x8", "taxi", "cliffwalking", "pong", "breakout", "spaceinvaders", "frozenlake_8x8_slippery", "taxi_full",
+         "blackjack", "blackjack_full"}
 
 
 def load(path):
@@ -37,7 +38,7 @@ def palette_index(frames):
 
 
 def test_fixtures_present():
-    assert len(FILES) == 19
+    assert len(FILES) == 21
 
 
 @pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f)[:-4] for f in FILES])

@@ -1,0 +1,159 @@
+"""Blackjack on the device (gx_blackjack.hip, through the C ABI) against the CPU oracle, bit for bit:
+the reference's ten-step stub (Envs.Blackjack.cs:21-40) and the upstream-rules extension
+(GX_BLACKJACK_FULL; parity unpinned: the reference has no such rules and `gymnasium` is not
+importable here, so the oracle's two restatements and hand-derived answers are the only pin)."""
+import numpy as np
+import pytest
+
+from gpu_common import L, make_pair, random_actions
+
+pytestmark = pytest.mark.gpu
+
+BJ = L.ENV_BLACKJACK
+RULES = [0, L.BLACKJACK_FULL]
+
+
+def same_state(g, o):
+    _, gi = g.get_state()
+    _, oi = o.get_state()
+    assert np.array_equal(gi, oi)
+    assert np.array_equal(g.get_obs(), o.get_obs())
+
+
+@pytest.mark.parametrize("rules", RULES, ids=["reference", "full"])
+def test_reset_and_steps_bit_exact(oracle, rules):
+    n = 4099  # ragged: not a multiple of the four envs a lane holds
+    g, o = make_pair(oracle, BJ, n, seed=41, flags=rules, base=6)  # base 6: lanes straddle generator blocks
+    assert g.info.n_int == 3 and g.info.obs_dim == 1 and g.info.action_n == 2
+    g.reset(); o.reset()
+    same_state(g, o)
+    rng = np.random.default_rng(1)
+    seen = set()
+    for t in range(14):  # no auto-reset: finished games are stepped on, as the reference's VectorEnv would
+        a = random_actions(rng, BJ, n, wide=True)
+        _, rew, done, _ = g.step_host(a)
+        orew, odone, _ = o.step(a)
+        assert np.array_equal(rew.astype(np.float64), orew) and np.array_equal(done, odone), t
+        same_state(g, o)
+        seen.update(zip((a[done > 0] != 0).tolist(), orew[done > 0].tolist()))
+        if t == 6:
+            g.reset(); o.reset()
+            same_state(g, o)
+    if rules:
+        assert seen >= {(True, -1.0), (False, -1.0), (False, 0.0), (False, 1.0)}
+    else:
+        assert seen == {(True, 1.0), (False, 1.0)}
+
+
+@pytest.mark.parametrize("rules", RULES, ids=["reference", "full"])
+@pytest.mark.parametrize("flags,time_limit", [(L.AUTORESET | L.RECORD_STATS, 0), (L.RECORD_STATS, 4), (L.AUTORESET | L.RECORD_STATS, 3), (L.AUTORESET, 0)])
+def test_fused_wrappers(oracle, rules, flags, time_limit):
+    n = 2051
+    g, o = make_pair(oracle, BJ, n, seed=13, flags=flags | rules, time_limit=time_limit, base=1 << 33)
+    g.reset(); o.reset()
+    rng = np.random.default_rng(6)
+    for t in range(45):
+        a = random_actions(rng, BJ, n)
+        _, rew, done, trunc = g.step_host(a, want_trunc=time_limit > 0)
+        orew, odone, otrunc = o.step(a)
+        assert np.array_equal(rew.astype(np.float64), orew) and np.array_equal(done, odone)
+        if time_limit:
+            assert np.array_equal(trunc, otrunc)
+        same_state(g, o)
+        if t == 20:
+            g.reset(); o.reset()
+    if flags & L.RECORD_STATS:
+        gs, os_ = g.stats(), o.stats()
+        assert gs.episodes == os_.episodes > 0 and gs.sum_length == os_.sum_length
+        assert gs.sum_return == os_.sum_return and gs.sum_return_sq == os_.sum_return_sq
+        assert gs.min_return == os_.min_return and gs.max_return == os_.max_return
+
+
+@pytest.mark.parametrize("rules", RULES, ids=["reference", "full"])
+@pytest.mark.parametrize("base", [0, 3])
+def test_random_policy_rollout_and_sampled_actions(oracle, rules, base):
+    """in-kernel Discrete(2).Sample(); K single steps == one K-step rollout == K oracle steps; the sampled-action
+    kernel replays the same policy"""
+    import torch
+    n, k = 3001, 24
+    flags = L.AUTORESET | L.RECORD_STATS | rules
+    g, o = make_pair(oracle, BJ, n, seed=99, flags=flags, base=base)
+    g2, _ = make_pair(oracle, BJ, n, seed=99, flags=flags, base=base)
+    g.reset(); o.reset(); g2.reset()
+    buf = torch.zeros(int(g.view().stride), dtype=torch.int32, device="cuda")
+    for t in range(k):
+        g.sample_actions(g.tick, buf.data_ptr())
+        g.ctx.synchronize()
+        a, _, _, _ = o.step_random()
+        assert np.array_equal(buf[:n].cpu().numpy(), a)
+        g.step_random()
+    g2.rollout(k)
+    g.ctx.synchronize()
+    same_state(g, o)
+    same_state(g2, o)
+    s1, s2, so = g.stats(), g2.stats(), o.stats()
+    for s in (s1, s2):
+        assert (s.episodes, s.sum_length, s.sum_return, s.sum_return_sq) == (so.episodes, so.sum_length, so.sum_return, so.sum_return_sq)
+    assert so.episodes > n
+
+
+def test_full_rules_known_answers_through_abi(oracle):
+    """hand-derived from upstream's rules: 21 against a dealer's ace over a ten is a draw and the dealer draws
+    nothing; hitting a hard 21 busts; a soft 17 that hits cannot bust"""
+    n = 512
+    g, _ = make_pair(oracle, BJ, n, seed=3, flags=L.BLACKJACK_FULL)
+    g.reset()
+    none = np.zeros((0, n), np.float32)
+    ints = np.zeros((3, n), np.int32)
+    ints[0] = (21 * 11 + 1) * 2 + 1
+    ints[1] = 10
+    g.set_state(none, ints)
+    _, rew, done, _ = g.step_host(np.zeros(n, np.int32))
+    assert done.all() and (rew == 0).all() and np.array_equal(g.get_state()[1][1], ints[1])
+    ints[0] = (21 * 11 + 5) * 2
+    ints[1] = 5
+    g.set_state(none, ints)
+    _, rew, done, _ = g.step_host(np.ones(n, np.int32))
+    assert done.all() and (rew == -1).all()
+    ints[0] = (21 * 11 + 6) * 2
+    ints[1] = 10  # dealer on 16 must draw; the player's 21 cannot lose
+    g.set_state(none, ints)
+    _, rew, done, _ = g.step_host(np.zeros(n, np.int32))
+    after = g.get_state()[1]
+    assert done.all() and (rew >= 0).all() and (rew == 1).any() and ((after[1] & 0xFF) > 10).all()
+    ints[0] = (17 * 11 + 2) * 2 + 1
+    g.set_state(none, ints)
+    _, rew, done, _ = g.step_host(np.full(n, 7, np.int32))  # any non-zero action hits
+    obs = g.get_obs()
+    total, usable = obs // 22, obs & 1
+    assert not done.any() and (rew == 0).all()
+    assert ((total == 17) & (usable == 0)).any() and ((total >= 18) & (total <= 21) & (usable == 1)).any()
+
+
+def test_full_rules_win_rate_is_plausible(oracle):
+    """a sanity check no restatement error could hide behind: sticking on everything from a fresh deal wins
+    about 38 % and loses about 57 % of the games under upstream's rules (dealer draws to 17)"""
+    n = 1 << 20
+    g, _ = make_pair(oracle, BJ, n, seed=5, flags=L.BLACKJACK_FULL)
+    g.reset()
+    _, rew, done, _ = g.step_host(np.zeros(n, np.int32))
+    assert done.all()
+    win, lose = (rew == 1).mean(), (rew == -1).mean()
+    assert 0.36 < win < 0.40 and 0.54 < lose < 0.59, (win, lose)
+
+
+def test_env_object_and_vector_env(oracle):
+    import gym_amd as G
+    env = G.Blackjack(full=True, seed=8)
+    s = env.Reset()
+    assert 4 <= s[0] <= 21 and 1 <= s[1] <= 10 and isinstance(s[2], bool)
+    s2, r, d, info = env.Step(0)
+    assert d and r in (-1.0, 0.0, 1.0) and s2 == s and info == {}
+    v = G.VectorEnv.Make(G.Blackjack, 300, seed=8, full=True, autoreset=True, record_stats=True)
+    o = oracle.OracleVec(oracle.BLACKJACK, 300, seed=8, flags=oracle.BLACKJACK_FULL | oracle.AUTORESET | oracle.RECORD_STATS)
+    v.Reset(); o.reset()
+    res = v.Step([1] * 300)
+    orew, odone, _ = o.step(np.ones(300, np.int32))
+    assert [x[1] for x in res] == list(orew) and [x[2] for x in res] == [bool(x) for x in odone]
+    oo = o.get_obs()
+    assert [x[0] for x in res] == [(int(i) // 22, (int(i) // 2) % 11, bool(i & 1)) for i in oo]

@@ -22,6 +22,8 @@ CASES = [
     (L.ENV_FROZENLAKE, FUSED | L.SLIPPERY, 0, L.MODE_EXACT, "device"),
     (L.ENV_CLIFFWALKING, L.RECORD_STATS, 9, L.MODE_EXACT, "random"),
     (L.ENV_DUMMY, FUSED, 0, L.MODE_EXACT, "random"),
+    (L.ENV_BLACKJACK, FUSED | L.BLACKJACK_FULL, 0, L.MODE_EXACT, "random"),
+    (L.ENV_BLACKJACK, FUSED, 7, L.MODE_EXACT, "device"),
     (L.ENV_PONG, FUSED, 0, L.MODE_EXACT, "random"),
     (L.ENV_BREAKOUT, L.AUTORESET, 25, L.MODE_EXACT, "device"),
 ]
@@ -81,7 +83,7 @@ def test_rollout_out_all_rows_equal_oracle_steps(oracle, env_id, flags, time_lim
     tv = torch_views(g)
     assert torch.equal(tv["done"][:n], done[k - 1, :n])
     assert torch.equal(tv["reward"][:n], rew[k - 1, :n])
-    if env_id in (L.ENV_CARTPOLE, L.ENV_FROZENLAKE, L.ENV_CLIFFWALKING, L.ENV_DUMMY, L.ENV_BREAKOUT):
+    if env_id in (L.ENV_CARTPOLE, L.ENV_FROZENLAKE, L.ENV_CLIFFWALKING, L.ENV_DUMMY, L.ENV_BREAKOUT, L.ENV_BLACKJACK):
         assert odone.any() and not odone.all()
     if env_id == L.ENV_PONG:
         assert (orew != 0).any()  # points were scored inside the rollout

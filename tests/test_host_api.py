@@ -44,7 +44,7 @@ def test_registry():
     G.RegisterAll()
     ids = G.EnvRegistry.List()
     for i in ("CartPole-v1", "MountainCar-v0", "MountainCarContinuous-v0", "Acrobot-v1", "Pendulum-v1",
-              "FrozenLake-v1", "Taxi-v3", "CliffWalking-v0", "Pong-v4"):
+              "FrozenLake-v1", "Taxi-v3", "CliffWalking-v0", "Blackjack-v1", "Pong-v4"):
         assert i in ids
     env = G.EnvRegistry.Make("CartPole-v1")
     assert isinstance(env, G.CartPole)
@@ -67,6 +67,7 @@ def test_space_declarations():
     assert G.FrozenLake().ObservationSpace.N == 16 and G.FrozenLake(["SFG", "HFF"]).ObservationSpace.N == 6
     assert G.Taxi().ActionSpace.N == 6 and G.Taxi().ObservationSpace.N == 500
     assert G.CliffWalking().ObservationSpace.N == 48
+    assert G.Blackjack().ActionSpace.N == 2 and G.Blackjack().ObservationSpace.N == 32 * 11 * 2  # Envs.Blackjack.cs:12-13
     p = G.Pong()
     assert p.ActionSpace.N == 4 and p.ObservationSpace.Dimension == 210 * 160 * 3 and p.RewardRange == (-1, 1)
 
@@ -153,6 +154,16 @@ def test_reference_shape_tests_on_device():
     assert info == {"score": 0, "lives": 3, "aliens_remaining": 55, "player_x": 76.0}
     G.RegisterAll()  # GymnasiumRegistration.cs:22-24
     assert isinstance(G.EnvRegistry.Make("Breakout-v4"), G.Breakout) and isinstance(G.EnvRegistry.Make("SpaceInvaders-v4"), G.SpaceInvaders)
+    env = G.Blackjack()  # Envs.Blackjack.cs:21-40: (sum, dealer card, usable ace); ten steps, then reward 1
+    s0 = env.Reset()
+    assert 12 <= s0[0] <= 21 and 1 <= s0[1] <= 10 and isinstance(s0[2], bool)
+    outs = [env.Step(t & 1) for t in range(10)]
+    assert all(o[0] == s0 for o in outs) and [o[2] for o in outs] == [False] * 9 + [True]
+    assert [o[1] for o in outs] == [0.0] * 9 + [1.0]
+    # envs built side by side without a seed are distinct, like the reference's unseeded Random per env
+    firsts = {G.CartPole().Reset() for _ in range(4)}
+    assert len(firsts) == 4
+    assert G.CartPole(seed=5).Reset() == G.CartPole(seed=5).Reset()
     env = G.DummyEnv()  # DummyEnvTests.cs:6-21
     assert env.Reset() == 0
     s, r, d, _ = env.Step(1)

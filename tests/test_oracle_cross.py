@@ -167,6 +167,93 @@ def test_frozenlake_slippery_extension_bitwise(oracle):
     assert counts.min() > 0.9 * counts.sum() / 12 and counts.max() < 1.1 * counts.sum() / 12
 
 
+def test_blackjack_reference_stub_bitwise(oracle):
+    """Envs.Blackjack.cs:21-40: three reset draws, a state that never changes, reward 1 at step ten"""
+    n = 500
+    v = oracle.OracleVec(oracle.BLACKJACK, n, seed=SEED)
+    v.reset()
+    env = np.arange(n, dtype=np.uint64)
+    ps, dc, ua = NP.blackjack_reset(SEED, env, 0)
+    assert ps.min() >= 12 and ps.max() <= 21 and dc.min() >= 1 and dc.max() <= 10 and set(ua) == {0, 1}
+    obs0 = ((ps * 11 + dc) * 2 + ua).astype(np.int32)
+    assert np.array_equal(v.get_obs(), obs0) and obs0.max() < 32 * 11 * 2
+    steps = np.zeros(n, np.int32)
+    rng = np.random.default_rng(4)
+    for t in range(12):
+        rew, done, _ = v.step(rng.integers(-1, 3, n).astype(np.int32))
+        steps, rew2, done2 = NP.blackjack_step(steps)
+        assert np.array_equal(rew, rew2) and np.array_equal(done.astype(bool), done2)
+        assert np.array_equal(v.get_obs(), obs0)
+        assert done.all() == (t >= 9) and rew.sum() == (n if t >= 9 else 0)
+    _, ints = v.get_state()
+    assert np.array_equal(ints[0], obs0) and not ints[1].any() and (ints[2] == 12).all()
+
+
+def test_blackjack_full_rules_extension_bitwise(oracle):
+    """upstream Blackjack-v1 rules (an extension): the C restatement keeps (sum, usable ace) and the
+    face-down cards' sum, the numpy one keeps whole hands as lists; states, rewards and flags agree"""
+    n = 3000
+    v = oracle.OracleVec(oracle.BLACKJACK, n, seed=SEED, flags=oracle.BLACKJACK_FULL)
+    env = np.arange(n, dtype=np.uint64)
+    rng = np.random.default_rng(12)
+    seen = set()
+    for episode in range(6):
+        v.reset()
+        tick = v.tick - 1
+        hands = NP.blackjack_full_deal(SEED, env, tick)
+        steps = np.zeros(n, np.int32)
+        _, ints = v.get_state()
+        assert np.array_equal(ints, NP.blackjack_image(hands, steps))
+        for t in range(5):  # keeps stepping finished games, as a caller of the reference's VectorEnv may
+            a = rng.integers(0, 2, n).astype(np.int32) if episode else np.full(n, t < 1, np.int32)
+            tick = v.tick
+            rew, done, _ = v.step(a)
+            rew2, done2 = NP.blackjack_full_step(hands, a, SEED, env, tick)
+            steps += 1
+            assert np.array_equal(rew, rew2) and np.array_equal(done.astype(bool), done2), (episode, t)
+            _, ints = v.get_state()
+            assert np.array_equal(ints, NP.blackjack_image(hands, steps)), (episode, t)
+            seen.update(zip(a[done2 > 0].tolist(), rew2[done2 > 0].tolist()))
+    # busts, and sticks that lose, draw and win, all occurred
+    assert seen >= {(1, -1.0), (0, -1.0), (0, 0.0), (0, 1.0)}
+
+
+def test_blackjack_full_rules_known_answers(oracle):
+    """hand-derived from upstream's rules: a player on 21 who sticks never loses; a dealer showing an
+    ace over a face-down ten stands on 21 without drawing; hitting on a hard 21 always busts"""
+    n = 256
+    v = oracle.OracleVec(oracle.BLACKJACK, n, seed=3, flags=oracle.BLACKJACK_FULL)
+    v.reset()
+    ints = np.zeros((3, n), np.int32)
+    ints[0] = (21 * 11 + 1) * 2 + 1   # player ace + ten, dealer shows an ace
+    ints[1] = 10                      # ... over a ten: dealer 21
+    v.set_state(np.zeros((0, n), np.float32), ints)
+    rew, done, _ = v.step(np.zeros(n, np.int32))
+    assert done.all() and (rew == 0.0).all()
+    _, after = v.get_state()
+    assert np.array_equal(after[1], ints[1])  # the dealer drew nothing
+    ints[0] = (21 * 11 + 5) * 2 + 0   # hard 21
+    ints[1] = 5
+    v.set_state(np.zeros((0, n), np.float32), ints)
+    rew, done, _ = v.step(np.ones(n, np.int32))
+    assert done.all() and (rew == -1.0).all()
+    ints[0] = (21 * 11 + 6) * 2 + 0
+    ints[1] = 10                      # dealer 16: must draw; the player's 21 cannot lose
+    v.set_state(np.zeros((0, n), np.float32), ints)
+    rew, done, _ = v.step(np.zeros(n, np.int32))
+    _, after = v.get_state()
+    assert done.all() and (rew >= 0.0).all() and (rew == 1.0).any() and ((after[1] & 0xFF) > 10).all()
+    # a soft 17 (ace + 6) that hits cannot bust, and a drawn ten turns it into a hard 17
+    ints[0] = (17 * 11 + 2) * 2 + 1
+    v.set_state(np.zeros((0, n), np.float32), ints)
+    rew, done, _ = v.step(np.ones(n, np.int32))
+    obs = v.get_obs()
+    assert not done.any() and (rew == 0.0).all()
+    total, usable = obs // 22, obs & 1
+    assert ((total == 17) & (usable == 0)).any() and ((total >= 18) & (total <= 21) & (usable == 1)).any()
+    assert ((usable == 1) | (total <= 17)).all() and (total >= 12).all()
+
+
 def test_pong_bitwise(oracle):
     n = 300
     v = oracle.OracleVec(oracle.PONG, n, seed=SEED)
