@@ -29,14 +29,14 @@ def test_reset_and_steps_bit_exact(oracle, rules):
     same_state(g, o)
     rng = np.random.default_rng(1)
     seen = set()
-    for t in range(14):  # no auto-reset: finished games are stepped on, as the reference's VectorEnv would
+    for t in range(24):  # no auto-reset: finished games are stepped on, as the reference's VectorEnv would
         a = random_actions(rng, BJ, n, wide=True)
         _, rew, done, _ = g.step_host(a)
         orew, odone, _ = o.step(a)
         assert np.array_equal(rew.astype(np.float64), orew) and np.array_equal(done, odone), t
         same_state(g, o)
         seen.update(zip((a[done > 0] != 0).tolist(), orew[done > 0].tolist()))
-        if t == 6:
+        if t == 12:
             g.reset(); o.reset()
             same_state(g, o)
     if rules:
