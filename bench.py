@@ -108,13 +108,15 @@ B_ALG = {
     "pong": 60 + 60 + 4 + 4 + 4 + 4 + 1 + 100800,          # 100937
     "breakout": 72 + 72 + 4 + 4 + 4 + 4 + 1 + 100800,      # 100961
     "spaceinvaders": 140 + 140 + 4 + 4 + 4 + 4 + 1 + 100800,  # 101097
+    # observation index r+w, steps r+w, ep_return r+w, action, reward, done; --blackjack-full adds the face-down row r+w
+    "blackjack": 4 + 4 + 4 + 4 + 4 + 4 + 4 + 4 + 1,       # 33
 }
 # binary64 mode: the state rows double in width (read + write), nothing else changes
 B_ALG_FP64_EXTRA = {"cartpole": 32, "mountaincar": 16, "mountaincarcontinuous": 16, "pendulum": 24, "acrobot": 48}
 ENV_IDS = {"cartpole": L.ENV_CARTPOLE, "mountaincar": L.ENV_MOUNTAINCAR, "acrobot": L.ENV_ACROBOT,
            "mountaincarcontinuous": L.ENV_MOUNTAINCAR_CONT, "taxi": L.ENV_TAXI,
            "pendulum": L.ENV_PENDULUM, "frozenlake": L.ENV_FROZENLAKE, "pong": L.ENV_PONG, "breakout": L.ENV_BREAKOUT,
-           "spaceinvaders": L.ENV_SPACEINVADERS}
+           "spaceinvaders": L.ENV_SPACEINVADERS, "blackjack": L.ENV_BLACKJACK}
 FRAME_ENVS = ("pong", "breakout", "spaceinvaders")
 # FP64 operations per env-step of the RK4 Acrobot (4 derivative evaluations of
 # ~32 flops, 52 for the RK4 combination, ~16 for wrap/clamp/termination),
@@ -161,7 +163,8 @@ def cpu_baseline(env_name, target_seconds=12.0):
     from oracle import oracle as O
 
     eid = {"cartpole": O.CARTPOLE, "acrobot": O.ACROBOT, "mountaincar": O.MOUNTAINCAR, "pendulum": O.PENDULUM,
-           "taxi": O.TAXI, "mountaincarcontinuous": O.MOUNTAINCAR_CONT, "frozenlake": O.FROZENLAKE, "pong": O.PONG, "breakout": O.BREAKOUT, "spaceinvaders": O.SPACEINVADERS}[env_name]
+           "taxi": O.TAXI, "mountaincarcontinuous": O.MOUNTAINCAR_CONT, "frozenlake": O.FROZENLAKE, "pong": O.PONG, "breakout": O.BREAKOUT, "spaceinvaders": O.SPACEINVADERS,
+           "blackjack": O.BLACKJACK}[env_name]
     n = 1024 if env_name in FRAME_ENVS else 1 << 16
     secs, steps_done = O.bench_reference_shaped(eid, n, 8 if env_name in FRAME_ENVS else 16)
     rate = steps_done / max(secs, 1e-9)
@@ -179,7 +182,7 @@ def cpu_baseline_all_cores(env_name, target_seconds=5.0):
     structs, no result lists, one thread per core.  FrozenLake shares a map object and is skipped."""
     from oracle import oracle as O
 
-    if env_name in ("frozenlake", "taxi"):
+    if env_name in ("frozenlake", "taxi", "blackjack"):
         return None
     eid = {"cartpole": O.CARTPOLE, "acrobot": O.ACROBOT, "mountaincar": O.MOUNTAINCAR, "pendulum": O.PENDULUM,
            "mountaincarcontinuous": O.MOUNTAINCAR_CONT, "pong": O.PONG, "breakout": O.BREAKOUT, "spaceinvaders": O.SPACEINVADERS}[env_name]
@@ -220,6 +223,7 @@ def main():
     ap.add_argument("--map", default=None, help="FrozenLake only: '8x8' or rows joined by '/'")
     ap.add_argument("--slippery", action="store_true", help="FrozenLake only: the is_slippery extension")
     ap.add_argument("--taxi-full", action="store_true", help="Taxi only: upstream Taxi-v3 dynamics (extension)")
+    ap.add_argument("--blackjack-full", action="store_true", help="Blackjack only: upstream Blackjack-v1 rules (extension)")
     ap.add_argument("--rk4", action="store_true", help="Acrobot only: the RK4 / binary64 extension (upstream dynamics)")
     ap.add_argument("--rollout", type=int, default=1,
                     help="K > 1: every timed step is one fused K-step rollout launch (state stays in registers, "
@@ -271,6 +275,8 @@ def main():
         flags |= L.SLIPPERY
     if args.taxi_full:
         flags |= L.TAXI_FULL
+    if args.blackjack_full:
+        flags |= L.BLACKJACK_FULL
     k_roll = max(1, args.rollout)
     if k_roll > 1:
         args.policy = "random"
@@ -317,7 +323,7 @@ def main():
         # f64 state r+w, steps r+w, reward, done, derived f32 observation rows
         b_alg = 32 + 32 + 4 + 4 + 4 + 1 + 24
     else:
-        b_alg = B_ALG[args.env] - (4 if args.policy == "random" else 0) + (8 if args.taxi_full else 0)
+        b_alg = B_ALG[args.env] - (4 if args.policy == "random" else 0) + (8 if args.taxi_full or args.blackjack_full else 0)
         if fp64_state:
             b_alg += B_ALG_FP64_EXTRA[args.env]
     achieved = b_alg * n / (kernel_ms * 1e-3) / 1e9
@@ -326,12 +332,12 @@ def main():
     else:
         kind = "single-step kernel"
     name = args.env + (" RK4/fp64" if args.rk4 else "") + (" " + args.map if args.map else "") + \
-        (" slippery" if args.slippery else "") + (" full Taxi-v3" if args.taxi_full else "")
+        (" slippery" if args.slippery else "") + (" full Taxi-v3" if args.taxi_full else "") + (" upstream rules" if args.blackjack_full else "")
     out = {
         "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f64" if args.rk4 or fp64_state else "u8" if args.env in FRAME_ENVS else ("i32" if args.env == "frozenlake" else "f32"),
+        "dtype": "f64" if args.rk4 or fp64_state else "u8" if args.env in FRAME_ENVS else ("i32" if args.env in ("frozenlake", "taxi", "blackjack") else "f32"),
         "data": "synthetic",
         "config": {
             "workload": "%s VectorEnv.Step, %d envs/GPU, %s, auto-reset + RecordEpisodeStatistics fused, "
@@ -362,7 +368,7 @@ def main():
             from gym_amd.build import csrc_hash
 
             t = json.load(open(traffic_file)).get("%s:%d:%s" % (args.env, n, args.policy))
-            if t and not args.rk4 and k_roll == 1 and not (args.slippery or args.taxi_full or args.map or args.mode != "exact"):
+            if t and not args.rk4 and k_roll == 1 and not (args.slippery or args.taxi_full or args.blackjack_full or args.map or args.mode != "exact"):
                 if t.get("csrc_hash") == csrc_hash():
                     out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
                     out["roofline"]["traffic_source"] = t["source"]
@@ -386,6 +392,8 @@ def main():
             out["extra"] = extra
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.env)
+        if args.slippery or args.taxi_full or args.blackjack_full or args.rk4:
+            out["cpu_baseline"]["sample"] += "; the CPU loop runs the reference's own rules, not the extension timed on the GPU"
         allc = cpu_baseline_all_cores(args.env)
         if allc:
             out["cpu_baseline_all_cores"] = allc

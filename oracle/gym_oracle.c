@@ -2048,7 +2048,7 @@ double gxo_bench_reference_shaped(int env_id, uint64_t num_envs, int steps, uint
   if (!v) return -1.0;
   gxo_vec_reset(v);
   void* actions = malloc(num_envs * 4);
-  static const int nact[GXO_NUM_ENVS] = {2, 3, 0, 0, 3, 4, 6, 4, 4, 3, 4, 6};
+  static const int nact[GXO_NUM_ENVS] = {2, 3, 0, 0, 3, 4, 6, 4, 4, 3, 4, 6, 2};
   for (uint64_t i = 0; i < num_envs; i++) {
     if (v->action_is_float) {
       float lim = env_id == GXO_PENDULUM ? 2.0f : 1.0f;
