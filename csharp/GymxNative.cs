@@ -14,15 +14,17 @@ public enum GxStatus { Ok = 0, Invalid = 1, Hip = 2, Oom = 3, Unsupported = 4, R
 public enum GxEnvId
 {
     CartPole = 0, MountainCar = 1, MountainCarContinuous = 2, Pendulum = 3, Acrobot = 4,
-    FrozenLake = 5, Taxi = 6, CliffWalking = 7, Pong = 8, Dummy = 9, Breakout = 10, SpaceInvaders = 11
+    FrozenLake = 5, Taxi = 6, CliffWalking = 7, Pong = 8, Dummy = 9, Breakout = 10, SpaceInvaders = 11, Blackjack = 12
 }
 
 public enum GxMode { Exact = 0, Fast32 = 1, Fp64 = 2 }
 
 [Flags]
-public enum GxFlags : uint { None = 0, AutoReset = 1, RecordStats = 2, Slippery = 4, TaxiFull = 8, AcrobotRk4 = 16 }
+public enum GxFlags : uint { None = 0, AutoReset = 1, RecordStats = 2, Slippery = 4, TaxiFull = 8, AcrobotRk4 = 16, BlackjackFull = 64 }
 
 public enum GxPolicy { DeviceActions = 0, Random = 1 }
+
+public enum GxRolloutOut { Last = 0, All = 1, None = 2 }
 
 public enum GxDType { F32 = 0, F64 = 1, I32 = 2, U8 = 3 }
 
@@ -67,6 +69,17 @@ public struct GxStats
     public double SumReturnSq, MinReturn, MaxReturn;
 }
 
+// gx_rows: caller-owned device rows for gx_rows_step, the entry point that allocates nothing
+[StructLayout(LayoutKind.Sequential)]
+public struct GxRows
+{
+    public uint StructSize;
+    public int EnvId;
+    public ulong NumEnvs, Stride, Seed, EnvIndexBase, Tick;
+    public int Mode, StateBounded;
+    public IntPtr StateReal, Steps, EpReturn, Actions, Reward, Done, Stats, Error;
+}
+
 internal static unsafe partial class Native
 {
     private const string Lib = "gymx"; // resolves libgymx.so on Linux
@@ -91,6 +104,8 @@ internal static unsafe partial class Native
     [LibraryImport(Lib)] internal static partial int gx_vec_step_random(IntPtr vec, IntPtr stream);
     [LibraryImport(Lib)] internal static partial int gx_vec_device_view(IntPtr vec, out GxView view);
     [LibraryImport(Lib)] internal static partial int gx_vec_rollout(IntPtr vec, int kSteps, int policy, IntPtr dActions, IntPtr stream);
+    [LibraryImport(Lib)] internal static partial int gx_vec_rollout_out(IntPtr vec, int kSteps, int policy, IntPtr dActions, int @out, IntPtr dRewardRows, IntPtr dDoneRows, IntPtr dTruncatedRows, IntPtr stream);
+    [LibraryImport(Lib)] internal static partial int gx_rows_step(IntPtr ctx, GxRows* rows, int kSteps, IntPtr stream);
     [LibraryImport(Lib)] internal static partial int gx_vec_sample_actions(IntPtr vec, ulong tick, IntPtr dActions, IntPtr stream);
     [LibraryImport(Lib)] internal static partial int gx_vec_tick(IntPtr vec, out ulong tick);
     [LibraryImport(Lib)] internal static partial int gx_vec_stats(IntPtr vec, out GxStats stats);
@@ -129,10 +144,25 @@ internal sealed class ContextHandle : SafeHandle
     }
 }
 
+// A batch handle keeps its context alive: gx_vec_destroy synchronises the context's streams, and
+// gx_ctx_destroy refuses while batches exist, so the reference taken here is released only after
+// the batch is gone -- whatever order the finalizers run in.
 internal sealed class VecHandle : SafeHandle
 {
+    private ContextHandle? _owner;
+    private bool _ownerRef;
     public VecHandle() : base(IntPtr.Zero, true) { }
     public override bool IsInvalid => handle == IntPtr.Zero;
-    protected override bool ReleaseHandle() => Native.gx_vec_destroy(handle) == 0;
-    internal void Set(IntPtr p) => SetHandle(p);
+    protected override bool ReleaseHandle()
+    {
+        bool ok = Native.gx_vec_destroy(handle) == 0;
+        if (_ownerRef) { _owner!.DangerousRelease(); _ownerRef = false; }
+        return ok;
+    }
+    internal void Set(IntPtr p, ContextHandle owner)
+    {
+        _owner = owner;
+        owner.DangerousAddRef(ref _ownerRef);
+        SetHandle(p);
+    }
 }
