@@ -65,7 +65,8 @@ def build(force=False):
         results = list(ex.map(_compile, SOURCES))
     objs = [o for o, _ in results]
     if any(changed for _, changed in results) or not os.path.exists(LIB):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
+        # --no-undefined: a launcher declared in gx_launch.h but defined nowhere fails here, not at dlopen on the GPU box
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--no-undefined", "-o", LIB] + objs + ["-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s" % r.stderr[-4000:])

@@ -11,6 +11,9 @@
 // of the pixel position and the state, evaluated four pixels per lane.
 #pragma clang fp contract(off)
 
+#include <cstdio>
+#include <cstdlib>
+
 #include "gx_device.h"
 #include "gx_frame.h"
 #include "gx_frame_step.h"
@@ -158,61 +161,103 @@ struct BreakoutGame {
   static __device__ __forceinline__ int32_t steps(const State& s) { return s.steps; }
 };
 
-// One workgroup per env, one four-pixel group per lane and iteration.
-__global__ void __launch_bounds__(kBlock) breakout_raster_kernel(StepArgs a, uint8_t* __restrict__ frames) {
-  __shared__ uint32_t digit_rows[5][5];  // rows 10..14 of the frame as 160-bit masks
-  const uint64_t env = blockIdx.x;
+// The frame in 16-byte chunks (gx_frame.h), `split` consecutive workgroups of THREADS lanes per env.
+// Three rows in four hold nothing (everything but the score rows 10..14, the life markers 25..27, the brick
+// rows 60..95, the paddle rows 190..193 and the ball's two rows) and are stored as zeros after one row test.
+// Elsewhere a lane derives two six-pixel masks for its chunk -- white objects, and brick pixels of the row's
+// colour -- and spreads them to bytes: white is 0xFF in every channel, so it may simply be OR-ed over the
+// brick colour it hides (the reference paints bricks first and everything white after them,
+// Envs.Breakout.cs:229-285).
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) breakout_raster_kernel(StepArgs a, uint8_t* __restrict__ frames, int split) {
+  __shared__ uint32_t digit_rows[5][6];  // rows 10..14 as 160-bit masks, plus a zero word for the 64-bit window
+  // the parts of a frame are consecutive workgroups: workgroups in flight together write neighbouring memory
+  const uint64_t env = blockIdx.x / (uint32_t)split;
+  const int part = (int)(blockIdx.x % (uint32_t)split);
+  constexpr int kChunksPerRow = kScreenW * 3 / 16, kChunks = kFrameBytes / 16;
+  // A frame starts 16-byte but not cache-line aligned (100 800 = 787.5 x 128): the steps are laid on the frame
+  // buffer's own THREADS x 16-byte grid, the first and the last step of a frame partly masked, so that no
+  // cache line is written by two workgroups (consecutive workgroups run on different XCDs, each with its own L2).
+  const int head = (int)((env * (uint64_t)kChunks) & (THREADS - 1));
+  const int steps = (head + kChunks + THREADS - 1) / THREADS;
+  const int per_part = (steps + split - 1) / split;
+  const int c_first = part * per_part * THREADS - head, c_end = min(kChunks, (part + 1) * per_part * THREADS - head);
+  if (c_first >= c_end) return;
   const double* r = static_cast<const double*>(a.state_real);
   const int32_t* n = a.state_int;
-  const double paddleX = r[4 * a.stride + env];
-  const bool stuck = n[2 * a.stride + env] != 0;
+  // every load is issued before the first use: one round trip to memory per workgroup, not one per branch
+  const double ballX = r[env], ballY = r[a.stride + env], paddleX = r[4 * a.stride + env];
+  const int32_t stuck_word = n[2 * a.stride + env];
+  const int lives = n[a.stride + env], score = n[env];
+  // the 108 brick bits as two 64-bit halves (no indexed array: it would be placed in LDS)
+  const uint64_t bricks_lo = (uint64_t)(uint32_t)n[3 * a.stride + env] | ((uint64_t)(uint32_t)n[4 * a.stride + env] << 32);
+  const uint64_t bricks_hi = (uint64_t)(uint32_t)n[5 * a.stride + env] | ((uint64_t)(uint32_t)n[6 * a.stride + env] << 32);
+  const bool stuck = stuck_word != 0;
   // (int) casts truncate toward zero, Envs.Breakout.cs:263-274
   const int px = (int)paddleX;
-  const int bx = stuck ? (int)(paddleX + bk::kPaddleW / 2.0 - bk::kBallSize / 2.0) : (int)r[env];
-  const int by = stuck ? kScreenH - 30 : (int)r[a.stride + env];
-  const int lives = n[a.stride + env];
-  uint32_t bricks[4];
-#pragma unroll
-  for (int w = 0; w < 4; w++) bricks[w] = (uint32_t)n[(3 + w) * a.stride + env];
-  if (threadIdx.x < 25) digit_rows[threadIdx.x / 5][threadIdx.x % 5] = 0;
-  __syncthreads();
-  // Envs.Breakout.cs:306-314: character i of the score at x = 10 + 6 i, rows 10..14
-  if (threadIdx.x < 5) score_row_mask(digit_rows[threadIdx.x], n[env], threadIdx.x, 10, 6, false);
-  __syncthreads();
+  const int bx = (int)(stuck ? paddleX + bk::kPaddleW / 2.0 - bk::kBallSize / 2.0 : ballX);
+  const int by = stuck ? kScreenH - 30 : (int)ballY;
+  // the score rows 10..14 are chunks 300..449: only a workgroup that covers some of them builds their masks
+  if (c_first < 15 * kChunksPerRow && c_end > 10 * kChunksPerRow) {
+    if (threadIdx.x < 30) digit_rows[threadIdx.x / 6][threadIdx.x % 6] = 0;
+    __syncthreads();
+    // Envs.Breakout.cs:306-314: character i of the score at x = 10 + 6 i, rows 10..14
+    if (threadIdx.x < 5) score_row_mask(digit_rows[threadIdx.x], score, threadIdx.x, 10, 6, false);
+    __syncthreads();
+  }
 
-  uint8_t* frame = frames + env * (uint64_t)kFrameBytes;
-  for (int c = threadIdx.x; c < kGroupsPerFrame; c += kBlock) {
-    const int y = c / kGroupsPerRow, g = c - y * kGroupsPerRow;
-    uint32_t white = 0;
-    if (y >= kScreenH - 20 && y < kScreenH - 20 + bk::kPaddleH) white |= span_mask(px, bk::kPaddleW, g);
-    if (y == by || y == by + 1) white |= span_mask(bx, bk::kBallSize, g);
-    if (y >= 10 && y < 15) white |= (digit_rows[y - 10][g >> 3] >> (4 * (g & 7))) & 0xFu;
-    if (y >= 25 && y < 28) {
-      // life marker i covers x in [10 + 8 i, 16 + 8 i), Envs.Breakout.cs:281-284
+  constexpr int kBrickRowsPx = bk::kBrickRows * bk::kBrickH, kPaddleY = kScreenH - 20;
+  uint4* frame = reinterpret_cast<uint4*>(frames + env * (uint64_t)kFrameBytes);
+  for (int c = c_first + (int)threadIdx.x; c < c_end; c += THREADS) {
+    if (c < 0) continue;
+    const int y = c / kChunksPerRow, j = c - y * kChunksPerRow;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    const bool brick_row = (uint32_t)(y - bk::kBrickStartY) < (uint32_t)kBrickRowsPx;
+    if (brick_row || (uint32_t)(y - 10) < 5u || (uint32_t)(y - 25) < 3u || (uint32_t)(y - kPaddleY) < (uint32_t)bk::kPaddleH ||
+        (uint32_t)(y - by) < (uint32_t)bk::kBallSize) {
+      const int p0 = (16 * j) / 3, ph = j % 3;
+      uint32_t white = 0;
+      if ((uint32_t)(y - kPaddleY) < (uint32_t)bk::kPaddleH) white |= span_bits6(px, bk::kPaddleW, p0);
+      if ((uint32_t)(y - by) < (uint32_t)bk::kBallSize) white |= span_bits6(bx, bk::kBallSize, p0);
+      if ((uint32_t)(y - 10) < 5u) {
+        const uint32_t* d = digit_rows[y - 10];
+        const uint64_t win = (uint64_t)d[p0 >> 5] | ((uint64_t)d[(p0 >> 5) + 1] << 32);
+        white |= (uint32_t)(win >> (p0 & 31)) & 63u;
+      }
+      if ((uint32_t)(y - 25) < 3u) {
+        // life marker i covers x in [10 + 8 i, 16 + 8 i), Envs.Breakout.cs:281-284
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int x = 4 * g + i - 10;
-        if (x >= 0 && (x & 7) < 6 && (x >> 3) < lives) white |= 1u << i;
+        for (int q = 0; q < 6; q++) {
+          const int x = p0 + q - 10;
+          if (x >= 0 && (x & 7) < 6 && (x >> 3) < lives) white |= 1u << q;
+        }
+      }
+      v = expand_white6(white, ph);
+      if (brick_row) {
+        const int row = (y - bk::kBrickStartY) / bk::kBrickH, dy = (y - bk::kBrickStartY) - row * bk::kBrickH;
+        // the window's pixels lie in the 8-pixel cells cell_a (the first n_a of them) and cell_a + 1; a brick is
+        // drawn 7 pixels wide and 5 high, the last column and the last row of its cell stay black
+        const int cell_a = p0 >> 3, n_a = min(6, 8 - (p0 & 7));
+        const int bit_a = row * bk::kBrickCols + cell_a, bit_b = bit_a + 1;
+        const bool has_a = cell_a < bk::kBrickCols && (((bit_a < 64 ? bricks_lo : bricks_hi) >> (bit_a & 63)) & 1ull);
+        const bool has_b = cell_a + 1 < bk::kBrickCols && (((bit_b < 64 ? bricks_lo : bricks_hi) >> (bit_b & 63)) & 1ull);
+        const uint32_t first = (1u << n_a) - 1u;
+        uint32_t brick = (has_a ? first : 0u) | (has_b ? 63u & ~first : 0u);
+        brick &= ~(1u << (7 - (p0 & 7)));  // the pixel with x mod 8 == 7 (bit 7 - p0 mod 8; beyond the window when >= 6)
+        if (dy < bk::kBrickH - 1 && brick) {
+          // Envs.Breakout.cs:248-253, r | g << 8 | b << 16
+          const uint32_t rgb = row == 0 ? 0x0000FFu : row == 1 ? 0x00A5FFu : row == 2 ? 0x00FFFFu : row == 3 ? 0x00FF00u : row == 4 ? 0xFF0000u : 0x800080u;
+          // the colour repeated over the chunk: a 96-bit pattern of three bytes, shifted by the phase
+          const uint32_t w0 = rgb | (rgb << 24), w1 = (rgb >> 8) | (rgb << 16), w2 = (rgb >> 16) | (rgb << 8);
+          const uint32_t sh = 8u * (uint32_t)ph;
+          const uint32_t c0 = __builtin_amdgcn_alignbit(w1, w0, sh), c1 = __builtin_amdgcn_alignbit(w2, w1, sh);
+          const uint32_t c2 = __builtin_amdgcn_alignbit(w0, w2, sh);
+          const uint4 e = expand_white6(brick, ph);
+          v.x |= e.x & c0; v.y |= e.y & c1; v.z |= e.z & c2; v.w |= e.w & c0;
+        }
       }
     }
-    uint32_t brick_rgb = 0, brick_px = 0;
-    if (y >= bk::kBrickStartY && y < bk::kBrickStartY + bk::kBrickRows * bk::kBrickH && g < 2 * bk::kBrickCols) {
-      const int row = (y - bk::kBrickStartY) / bk::kBrickH, dy = (y - bk::kBrickStartY) - row * bk::kBrickH;
-      const int bit = row * bk::kBrickCols + (g >> 1);
-      uint32_t word = bricks[0];
-#pragma unroll
-      for (int w = 1; w < 4; w++) word = (bit >> 5) == w ? bricks[w] : word;
-      if (dy < bk::kBrickH - 1 && ((word >> (bit & 31)) & 1u)) {
-        // a brick is drawn 7 pixels wide: the last column of its 8-pixel cell stays black
-        brick_px = (g & 1) ? 0x7u : 0xFu;
-        // Envs.Breakout.cs:248-253, r | g << 8 | b << 16
-        brick_rgb = row == 0 ? 0x0000FFu : row == 1 ? 0x00A5FFu : row == 2 ? 0x00FFFFu : row == 3 ? 0x00FF00u : row == 4 ? 0xFF0000u : 0x800080u;
-      }
-    }
-    uint32_t col[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) col[i] = ((white >> i) & 1u) ? 0xFFFFFFu : (((brick_px >> i) & 1u) ? brick_rgb : 0u);
-    *reinterpret_cast<U3*>(frame + (uint64_t)c * 12) = pack_rgb4(col[0], col[1], col[2], col[3]);
+    frame[c] = v;
   }
 }
 
@@ -220,7 +265,22 @@ hipError_t launch_breakout_step(const StepArgs& a, int policy, dim3 grid, hipStr
 hipError_t launch_breakout_reset(const StepArgs& a, dim3 grid, hipStream_t stream) { return launch_frame_reset<BreakoutGame>(a, grid, stream); }
 hipError_t launch_breakout_raster(const StepArgs& a, uint8_t* frames, hipStream_t stream) {
   if (a.num_envs == 0) return hipSuccess;
-  hipLaunchKernelGGL(breakout_raster_kernel, dim3((unsigned)a.num_envs), dim3(kBlock), 0, stream, a, frames);
+  // tuning aid: GYMX_FRAME_RASTER=<threads>,<workgroups per frame>, threads 64, 128 or 256
+  // One 256-thread workgroup per frame.  Unlike Pong's, this raster gains nothing from shorter workgroups
+  // (65 536 envs, step + raster: 1.23 ms as is; 64 or 128 threads x 9..50 workgroups per frame 1.5-1.95 ms,
+  // and still 1.24-1.32 ms with the eleven state loads of a workgroup replaced by one packed record).
+  static int threads = 256, split = 1;
+  static const bool parsed = [] {
+    const char* s = std::getenv("GYMX_FRAME_RASTER");
+    int t = 0, sp = 0;
+    if (s && std::sscanf(s, "%d,%d", &t, &sp) == 2 && (t == 64 || t == 128 || t == 256) && sp >= 1 && sp <= 128) { threads = t; split = sp; }
+    return true;
+  }();
+  (void)parsed;
+  const dim3 grid((unsigned)(a.num_envs * (uint64_t)split));
+  if (threads == 64) hipLaunchKernelGGL(breakout_raster_kernel<64>, grid, dim3(64), 0, stream, a, frames, split);
+  else if (threads == 128) hipLaunchKernelGGL(breakout_raster_kernel<128>, grid, dim3(128), 0, stream, a, frames, split);
+  else hipLaunchKernelGGL(breakout_raster_kernel<256>, grid, dim3(256), 0, stream, a, frames, split);
   return hipGetLastError();
 }
 hipError_t launch_breakout_sample(const StepArgs& a, void* out, dim3 grid, hipStream_t stream) { return launch_frame_sample<BreakoutGame>(a, out, grid, stream); }

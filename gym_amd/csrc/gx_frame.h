@@ -35,6 +35,46 @@ __device__ __forceinline__ uint32_t span_mask(int x0, int w, int g) {
   return hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
 }
 
+// ---- 16-byte chunks -------------------------------------------------------
+// A frame is 6300 chunks of 16 bytes, a row 30 of them; chunk j of a row holds row bytes [16 j, 16 j + 16),
+// i.e. bytes of the six pixels p0 .. p0 + 5 with p0 = floor(16 j / 3), starting `phase` = 16 j mod 3 = j mod 3
+// bytes into pixel p0.
+struct Bytes16 {
+  uint32_t x, y, z, w;
+};
+// the sixteen bytes of chunk j of a row in which exactly the pixels [x0, x0 + w) are white
+constexpr Bytes16 chunk_bytes(int x0, int w, int j) {
+  uint32_t d[4] = {0, 0, 0, 0};
+  for (int i = 0; i < 16; i++) {
+    const int pixel = (16 * j + i) / 3;
+    if (pixel >= x0 && pixel < x0 + w) d[i >> 2] |= 0xFFu << (8 * (i & 3));
+  }
+  return Bytes16{d[0], d[1], d[2], d[3]};
+}
+
+__device__ __forceinline__ uint32_t span_bits6(int x0, int w, int p0) {
+  int lo = x0 - p0, hi = lo + w;
+  lo = lo < 0 ? 0 : lo;
+  hi = hi > 6 ? 6 : hi;
+  return hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
+}
+
+// six pixel bits -> the sixteen bytes that start `phase` bytes into the first pixel (0xFF per byte of a set pixel)
+__device__ __forceinline__ uint4 expand_white6(uint32_t m, int phase) {
+  // all-ones where the pixel's bit is set
+  const uint32_t b0 = 0u - (m & 1u), b1 = 0u - ((m >> 1) & 1u), b2 = 0u - ((m >> 2) & 1u);
+  const uint32_t b3 = 0u - ((m >> 3) & 1u), b4 = 0u - ((m >> 4) & 1u), b5 = 0u - ((m >> 5) & 1u);
+  // pixel q covers bits [24 q, 24 q + 24) of a 144-bit string
+  const uint32_t w0 = (b0 & 0x00FFFFFFu) | (b1 & 0xFF000000u);
+  const uint32_t w1 = (b1 & 0x0000FFFFu) | (b2 & 0xFFFF0000u);
+  const uint32_t w2 = (b2 & 0x000000FFu) | (b3 & 0xFFFFFF00u);
+  const uint32_t w3 = (b4 & 0x00FFFFFFu) | (b5 & 0xFF000000u);
+  const uint32_t w4 = b5 & 0x0000FFFFu;
+  const uint32_t sh = 8u * (uint32_t)phase;  // 0, 8 or 16
+  return make_uint4(__builtin_amdgcn_alignbit(w1, w0, sh), __builtin_amdgcn_alignbit(w2, w1, sh),
+                    __builtin_amdgcn_alignbit(w3, w2, sh), __builtin_amdgcn_alignbit(w4, w3, sh));
+}
+
 // Row `row` (0..4) of the 3x5 digit glyphs, bit dx = column dx.  The table of
 // Envs.Pong.cs:228-237 and Envs.Breakout.cs:321-330 (identical), 3 bits per row.
 __device__ __forceinline__ uint32_t glyph_row(uint32_t digit, int row) {

@@ -4,10 +4,13 @@
 // The reference clears a 100 800-byte array and draws ~30 rectangles with
 // per-pixel bounds checks on every step (Envs.Pong.cs:167-209).  Every drawn
 // pixel is (255,255,255), so draw order is irrelevant and the frame is a
-// binary mask: each lane derives four consecutive pixels of a row from the
-// object positions and writes them as one 12-byte store, a workgroup writing
-// one env's frame front to back with fully coalesced stores.
+// binary mask: each lane derives the six pixels that touch its sixteen bytes of
+// a row from the object positions and writes them as one 16-byte store; a frame
+// is written by 17 consecutive two-wave workgroups.
 #pragma clang fp contract(off)
+
+#include <cstdio>
+#include <cstdlib>
 
 #include "gx_device.h"
 #include "gx_frame.h"
@@ -115,42 +118,79 @@ struct PongGame {
   static __device__ __forceinline__ int32_t steps(const State& s) { return s.steps; }
 };
 
-// One workgroup per env.  A frame row is 160 pixels = 40 groups of four
-// pixels = 40 lanes x 12 bytes; the frame is 8400 such groups.
-__global__ void __launch_bounds__(kBlock) pong_raster_kernel(StepArgs a, uint8_t* __restrict__ frames) {
-  __shared__ uint32_t digit_rows[5][5];  // rows 20..24 of the frame as 160-bit masks
-  const uint64_t env = blockIdx.x;
+// One 16-byte store per lane.  A frame is 6300 chunks of 16 bytes, a row 30 of them;
+// chunk j of a row holds row bytes [16 j, 16 j + 16), i.e. bytes of the six pixels p0 .. p0 + 5 with
+// p0 = floor(16 j / 3), starting `phase` = 16 j mod 3 = j mod 3 bytes into pixel p0.  A lane derives the six
+// pixel bits from the object positions and spreads them to sixteen bytes with a few bit operations.
+// grid = (envs, split): workgroup (env, part) writes its share of the env's frame in steps of THREADS x 16
+// bytes.  A frame starts 16-byte but not 4 KiB aligned (100 800 = 24 x 4096 + 2496), so the steps are laid
+// on the frame buffer's own THREADS x 16-byte grid -- the first and the last step of a frame partly masked --
+// and every wave's 1 KiB store lies within one aligned block.
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) pong_raster16_kernel(StepArgs a, uint8_t* __restrict__ frames, int split) {
+  __shared__ uint32_t digit_rows[5][6];  // rows 20..24 as 160-bit masks, plus a zero word for the 64-bit window
+  // the parts of a frame are consecutive workgroups: workgroups in flight together write neighbouring memory
+  const uint64_t env = blockIdx.x / (uint32_t)split;
+  const int part = (int)(blockIdx.x % (uint32_t)split);
+  constexpr int kChunksPerRow = kScreenW * 3 / 16, kChunks = kFrameBytes / 16;
+  const int head = (int)((env * (uint64_t)kChunks) & (THREADS - 1));
+  const int nsteps = (head + kChunks + THREADS - 1) / THREADS;
+  const int per_part = (nsteps + split - 1) / split;
+  const int step0 = part * per_part, step1 = min(nsteps, step0 + per_part);
+  if (step0 >= step1) return;
+  const int c_first = step0 * THREADS - head, c_end = min(kChunks, step1 * THREADS - head);
+
   const double* r = static_cast<const double*>(a.state_real);
   // (int) casts truncate toward zero, Envs.Pong.cs:173-179
   const int bx = (int)r[env], by = (int)r[a.stride + env];
   const int ly = (int)r[4 * a.stride + env], ry = (int)r[5 * a.stride + env];
-  if (threadIdx.x < 25) digit_rows[threadIdx.x / 5][threadIdx.x % 5] = 0;
-  __syncthreads();
-  if (threadIdx.x < 10) {
-    // Envs.Pong.cs:211-251: decimal string centred on centerX, digit i at startX + 8 i, rows 20..24
-    const int side = threadIdx.x / 5, row = threadIdx.x % 5;
-    const int score = a.state_int[(uint64_t)side * a.stride + env];
-    score_row_mask(digit_rows[row], score, row, side ? 3 * kScreenW / 4 : kScreenW / 4, 8, true);
-  }
-  __syncthreads();
-
-  uint8_t* frame = frames + env * (uint64_t)kFrameBytes;
-  for (int c = threadIdx.x; c < kScreenH * 40; c += kBlock) {
-    const int y = c / 40, g = c - y * 40;
-    uint32_t nib = 0;
-    if (g == 0 && y >= ly && y < ly + kPaddleH) nib |= 0x3u;           // left paddle, x in {0,1}
-    if (g == 39 && y >= ry && y < ry + kPaddleH) nib |= 0xCu;          // right paddle, x in {158,159}
-    if ((y & 7) < 4) nib |= g == 19 ? 0x8u : (g == 20 ? 0x1u : 0u);    // centre dashes, x in {79,80}
-    if (y == by || y == by + 1) {                                      // ball, x in {bx, bx+1}
-      const int rel = bx - 4 * g;
-      if (rel >= -1 && rel <= 3) nib |= ((0x3u << (rel + 1)) >> 1) & 0xFu;
+  // the score rows 20..24 are chunks 600..749: only a workgroup that covers some of them builds their masks
+  if (c_first < 25 * kChunksPerRow && c_end > 20 * kChunksPerRow) {
+    if (threadIdx.x < 30) digit_rows[threadIdx.x / 6][threadIdx.x % 6] = 0;
+    __syncthreads();
+    if (threadIdx.x < 10) {
+      // Envs.Pong.cs:211-251: decimal string centred on centerX, digit i at startX + 8 i, rows 20..24
+      const int side = threadIdx.x / 5, row = threadIdx.x % 5;
+      const int score = a.state_int[(uint64_t)side * a.stride + env];
+      score_row_mask(digit_rows[row], score, row, side ? 3 * kScreenW / 4 : kScreenW / 4, 8, true);
     }
-    if (y >= 20 && y < 25) nib |= (digit_rows[y - 20][g >> 3] >> (4 * (g & 7))) & 0xFu;
-    // four pixels -> twelve bytes, three bytes of 0xFF per set pixel
-    const uint32_t white = 0x00FFFFFFu;
-    *reinterpret_cast<U3*>(frame + (uint64_t)c * 12) =
-        pack_rgb4((0u - (nib & 1u)) & white, (0u - ((nib >> 1) & 1u)) & white, (0u - ((nib >> 2) & 1u)) & white,
-                  (0u - ((nib >> 3) & 1u)) & white);
+    __syncthreads();
+  }
+
+  uint4* frame = reinterpret_cast<uint4*>(frames + env * (uint64_t)kFrameBytes);
+  // The paddles and the centre line sit in fixed chunks of a row (0, 29, and 14 / 15), so their sixteen bytes
+  // are compile-time constants selected by the chunk index and one row test; only the ball's two rows and the
+  // five score rows go through the general pixel-window path, which a wave skips when none of its lanes is
+  // in such a row.  (40 vector instructions per 16-byte store; the general path for every chunk took 88.)
+  constexpr int kRightChunk = kChunksPerRow - 1, kDashChunkA = (3 * (kScreenW / 2 - 1)) / 16, kDashChunkB = (3 * (kScreenW / 2)) / 16;
+  constexpr Bytes16 kLeft = chunk_bytes(0, kPaddleW, 0), kRight = chunk_bytes(kScreenW - kPaddleW, kPaddleW, kRightChunk);
+  constexpr Bytes16 kDashA = chunk_bytes(kScreenW / 2 - 1, 1, kDashChunkA), kDashB = chunk_bytes(kScreenW / 2, 1, kDashChunkB);
+  static_assert(kDashChunkA == 14 && kDashChunkB == 15 && kLeft.z == 0 && kLeft.w == 0 && kRight.x == 0 && kRight.y == 0 &&
+                kDashA.x == 0 && kDashA.y == 0 && kDashA.z == 0 && kDashB.y == 0 && kDashB.z == 0 && kDashB.w == 0, "chunk layout");
+  for (int c = c_first + (int)threadIdx.x; c < c_end; c += THREADS) {
+    if (c < 0) continue;
+    const int y = c / kChunksPerRow, j = c - y * kChunksPerRow;
+    const bool left = j == 0 && (uint32_t)(y - ly) < (uint32_t)kPaddleH;            // left paddle, x in {0,1}
+    const bool right = j == kRightChunk && (uint32_t)(y - ry) < (uint32_t)kPaddleH;  // right paddle, x in {158,159}
+    const bool dash = (y & 7) < 4;                                                    // centre dashes, x in {79,80}
+    uint4 v;
+    v.x = left ? kLeft.x : (dash && j == kDashChunkB ? kDashB.x : 0u);
+    v.y = left ? kLeft.y : 0u;
+    v.z = right ? kRight.z : 0u;
+    v.w = right ? kRight.w : (dash && j == kDashChunkA ? kDashA.w : 0u);
+    if ((uint32_t)(y - by) < (uint32_t)kBallSize || (uint32_t)(y - 20) < 5u) {
+      const int p0 = (16 * j) / 3, ph = j % 3;
+      uint32_t m = 0;
+      if ((uint32_t)(y - by) < (uint32_t)kBallSize) m |= span_bits6(bx, kBallSize, p0);  // ball, x in {bx, bx+1}
+      if ((uint32_t)(y - 20) < 5u) {
+        const uint32_t* d = digit_rows[y - 20];
+        const uint64_t win = (uint64_t)d[p0 >> 5] | ((uint64_t)d[(p0 >> 5) + 1] << 32);
+        m |= (uint32_t)(win >> (p0 & 31)) & 63u;
+      }
+      const uint4 e = expand_white6(m, ph);
+      v.x |= e.x; v.y |= e.y; v.z |= e.z; v.w |= e.w;
+    }
+    frame[c] = v;
   }
 }
 
@@ -158,7 +198,22 @@ hipError_t launch_pong_step(const StepArgs& a, int policy, dim3 grid, hipStream_
 hipError_t launch_pong_reset(const StepArgs& a, dim3 grid, hipStream_t stream) { return launch_frame_reset<PongGame>(a, grid, stream); }
 hipError_t launch_pong_raster(const StepArgs& a, uint8_t* frames, hipStream_t stream) {
   if (a.num_envs == 0) return hipSuccess;
-  hipLaunchKernelGGL(pong_raster_kernel, dim3((unsigned)a.num_envs), dim3(kBlock), 0, stream, a, frames);
+  // 17 consecutive two-wave workgroups per frame, three 2 KiB steps each.  Measured at 65 536 envs (step +
+  // raster, ms): one 256-thread workgroup walking a whole frame 1.21; 64 threads x 10..25 workgroups per
+  // frame 1.20; 64 x 34 and 128 x 17 (three steps per wave) 1.09; 64 x 50 and 128 x 25 (two steps) 1.35.
+  // Tuning aid: GYMX_PONG_RASTER=<threads>,<workgroups per frame>, threads 64, 128 or 256.
+  static int threads = 128, split = 17;
+  static const bool parsed = [] {
+    const char* s = std::getenv("GYMX_PONG_RASTER");
+    int t = 0, sp = 0;
+    if (s && std::sscanf(s, "%d,%d", &t, &sp) == 2 && (t == 64 || t == 128 || t == 256) && sp >= 1 && sp <= 128) { threads = t; split = sp; }
+    return true;
+  }();
+  (void)parsed;
+  const dim3 grid((unsigned)(a.num_envs * (uint64_t)split));
+  if (threads == 64) hipLaunchKernelGGL(pong_raster16_kernel<64>, grid, dim3(64), 0, stream, a, frames, split);
+  else if (threads == 128) hipLaunchKernelGGL(pong_raster16_kernel<128>, grid, dim3(128), 0, stream, a, frames, split);
+  else hipLaunchKernelGGL(pong_raster16_kernel<256>, grid, dim3(256), 0, stream, a, frames, split);
   return hipGetLastError();
 }
 hipError_t launch_pong_sample(const StepArgs& a, void* out, dim3 grid, hipStream_t stream) { return launch_frame_sample<PongGame>(a, out, grid, stream); }
