@@ -228,6 +228,9 @@ def main():
     ap.add_argument("--rollout", type=int, default=1,
                     help="K > 1: every timed step is one fused K-step rollout launch (state stays in registers, "
                          "actions sampled in-kernel); env-steps are counted as envs x K per launch")
+    ap.add_argument("--rollout-out", default="last", choices=["last", "all", "none"],
+                    help="with --rollout K: what the fused rollout hands back -- the last step's reward / done rows, every "
+                         "step's (written to [K][stride] device rows, 5 or 9 more bytes per env-step), or statistics only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary Acrobot measurements")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -290,10 +293,20 @@ def main():
     batch.reset()
     stream_ptr = torch.cuda.current_stream().cuda_stream
     view = batch.view()
+    out_rows = None
+    if k_roll > 1 and args.rollout_out == "all":
+        rdt = torch.float64 if batch.info.reward_dtype == L.F64 else torch.float32
+        out_rows = (torch.empty((k_roll, int(view.stride)), dtype=rdt, device="cuda"),
+                    torch.empty((k_roll, int(view.stride)), dtype=torch.uint8, device="cuda"))
     if k_roll > 1:
         def step_fn():
             # one fused rollout, then the episode statistics reduced on the device and across ranks
-            batch.rollout(k_roll, L.POLICY_RANDOM, None, stream_ptr)
+            if args.rollout_out == "all":
+                batch.rollout_out(k_roll, L.OUT_ALL, L.POLICY_RANDOM, None, out_rows[0].data_ptr(), out_rows[1].data_ptr(), None, stream_ptr)
+            elif args.rollout_out == "none":
+                batch.rollout_out(k_roll, L.OUT_NONE, L.POLICY_RANDOM, None, None, None, None, stream_ptr)
+            else:
+                batch.rollout(k_roll, L.POLICY_RANDOM, None, stream_ptr)
             if dist is not None:
                 torch.cuda.current_stream().synchronize()
                 allreduce_stats(batch.stats(), dist, device=COLLECTIVE_DEVICE)
@@ -326,9 +339,14 @@ def main():
         b_alg = B_ALG[args.env] - (4 if args.policy == "random" else 0) + (8 if args.taxi_full or args.blackjack_full else 0)
         if fp64_state:
             b_alg += B_ALG_FP64_EXTRA[args.env]
-    achieved = b_alg * n / (kernel_ms * 1e-3) / 1e9
     if k_roll > 1:
-        kind = "fused %d-step rollout kernel (one launch per timed step)" % k_roll
+        # per env-step of a K-step rollout: the rows are read and written once per launch; the last step's reward /
+        # done rows, or every step's
+        rew_b = 8 if batch.info.reward_dtype == L.F64 else 4
+        b_alg = (b_alg - rew_b - 1) / k_roll + {"last": (rew_b + 1) / k_roll, "all": (rew_b + 1) * (1 + 1 / k_roll), "none": 0.0}[args.rollout_out]
+    achieved = b_alg * n * k_roll / (kernel_ms * 1e-3) / 1e9
+    if k_roll > 1:
+        kind = "fused %d-step rollout kernel (one launch per timed step; reward / done rows handed back: %s)" % (k_roll, args.rollout_out)
     else:
         kind = "single-step kernel"
     name = args.env + (" RK4/fp64" if args.rk4 else "") + (" " + args.map if args.map else "") + \
@@ -348,7 +366,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                      "kernel_ms": kernel_ms, "bytes_per_env_step": b_alg,
-                     "algorithmic_bytes_per_launch": b_alg * n},
+                     "algorithmic_bytes_per_launch": b_alg * n * k_roll},
     }
     if args.rk4 and k_roll > 1:
         # the fused rollout is bound by the FP64 vector ALU, not by HBM: flops as the SQ counters

@@ -1,10 +1,11 @@
 #!/bin/bash
 # Runs on the GPU box (through gpurun): kernel-trace stats of the default bench run, then the
 # two HBM-traffic counter passes, each in its own rocprofv3 run.  Output under gpurun_out/prof/.
-# usage: tools/collect_profiles.sh [bench args...]
+# usage: [PROF_DIR=name] tools/collect_profiles.sh [bench args...]
 set -e
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-OUT=$R/gpurun_out/prof
+OUT=$R/gpurun_out/${PROF_DIR:-prof}
+rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq  # a run's files only
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline $*"
