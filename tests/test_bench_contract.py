@@ -42,3 +42,14 @@ def test_rollout_workload_line():
     j = _run("--env", "acrobot", "--rk4", "--rollout", "8", "--num-envs", "65536", "--no-cpu-baseline")
     assert j["dtype"] == "f64" and j["roofline"]["bound"] == "fp64-valu" and j["roofline"]["unit"] == "TFLOP/s"
     assert abs(j["value"] - 65536 * 8 * 5 / (j["ms_per_step"] * 5e-3)) / j["value"] < 1e-6
+
+
+@pytest.mark.gpu
+def test_plain_launch_with_two_ranks():
+    """`python bench.py --gpus 2` with no launcher around it starts its own two ranks (here both on the one GPU of
+    the test box, collectives over gloo) and prints one line for the whole job"""
+    j = _run("--gpus", "2", "--share-device", "--dist-backend", "gloo", "--num-envs", "262144", "--no-extra")
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and "cpu_baseline" not in j
+    # whole-job value: both ranks' envs over the slowest rank's time
+    assert abs(j["value"] - 2 * 262144 * 5 / (j["ms_per_step"] * 5e-3)) / j["value"] < 1e-6
+    assert j["episode_stats"]["episodes"] >= 0  # six steps: no CartPole episode is over yet
