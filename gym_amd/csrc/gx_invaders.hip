@@ -249,33 +249,24 @@ __device__ __forceinline__ uint32_t palette(uint32_t idx) {
          idx == kRed ? 0x0000FFu : idx == kWhite ? 0xFFFFFFu : 0u;
 }
 
-// One workgroup per env, one four-pixel group per lane and iteration; nothing is staged: a
-// lane decides the colour of its four pixels from the game state.  The layers are applied in the
+// One workgroup per env, one 16-byte chunk (six pixels' bytes) per lane and iteration; nothing is staged: a
+// lane decides what its chunk holds from the game state.  The layers are applied in the
 // source's drawing order (Envs.SpaceInvaders.cs:355-411: aliens, cannon, player bullets, alien
 // bullets, score, lives, ground line), a later layer overwriting an earlier one, which is what
 // painting into a frame does; a pixel off the screen is never visited, which is the reference's
 // DrawRectangle bounds check (:461-478).
 __global__ void __launch_bounds__(kBlock) invaders_raster_kernel(StepArgs a, uint8_t* __restrict__ frames) {
-  __shared__ uint32_t digit_rows[5][5];  // rows 10..14 of the frame as 160-bit masks (the score)
+  __shared__ uint32_t digit_rows[5][6];  // rows 10..14 of the frame as 160-bit masks (the score), plus a zero word for the 64-bit window
   __shared__ int32_t alien_x[si::kCols], alien_y[si::kRows];
   __shared__ uint8_t row_layers[kScreenH];  // which layers can touch a frame row (most rows: none)
   const uint64_t env = blockIdx.x;
   const int tid = threadIdx.x;
   const double* r = static_cast<const double*>(a.state_real);
   const int32_t* n = a.state_int;
+  // every load is issued before the first barrier: one round trip to memory per workgroup
   const double formX = r[a.stride + env], formY = r[2 * a.stride + env];
-  // column / row origins exactly as the source computes them, (int)(formation + 12 col) and
-  // (int)(formation + 10 row): the cast truncates toward zero, so consecutive origins are 12 (10)
-  // apart give or take one
-  if (tid < si::kCols) alien_x[tid] = (int)(formX + tid * 12);
-  if (tid < si::kRows) alien_y[tid] = (int)(formY + tid * 10);
-  if (tid >= 32 && tid < 57) digit_rows[(tid - 32) / 5][(tid - 32) % 5] = 0;
-  __syncthreads();
-  // score, :403, 480-525: character i at x = 10 + 6 i, rows 10..14
-  if (tid < 5) score_row_mask(digit_rows[tid], n[env], tid, 10, 6, false);
-
+  const int32_t score = n[env];
   const uint64_t aliens = (uint64_t)(uint32_t)n[6 * a.stride + env] | ((uint64_t)(uint32_t)n[7 * a.stride + env] << 32);
-  const int x0 = alien_x[0], y0 = alien_y[0], y_end = alien_y[si::kRows - 1] + 6;
   const int player_x = (int)r[env];
   const int lives = n[a.stride + env];
   const int shown = lives < 0 ? 0 : (lives > 13 ? 13 : lives);  // cannon 13 would start at x = -10
@@ -287,6 +278,16 @@ __global__ void __launch_bounds__(kBlock) invaders_raster_kernel(StepArgs a, uin
   for (int b = 0; b < si::kMaxPB; b++) { pbx[b] = (int)r[(3 + 2 * b) * a.stride + env]; pby[b] = (int)r[(4 + 2 * b) * a.stride + env]; }
 #pragma unroll
   for (int b = 0; b < si::kMaxAB; b++) { abx[b] = (int)r[(9 + 2 * b) * a.stride + env]; aby[b] = (int)r[(10 + 2 * b) * a.stride + env]; }
+  // column / row origins exactly as the source computes them, (int)(formation + 12 col) and
+  // (int)(formation + 10 row): the cast truncates toward zero, so consecutive origins are 12 (10)
+  // apart give or take one
+  if (tid < si::kCols) alien_x[tid] = (int)(formX + tid * 12);
+  if (tid < si::kRows) alien_y[tid] = (int)(formY + tid * 10);
+  if (tid >= 32 && tid < 62) digit_rows[(tid - 32) / 6][(tid - 32) % 6] = 0;
+  __syncthreads();
+  // score, :403, 480-525: character i at x = 10 + 6 i, rows 10..14
+  if (tid < 5) score_row_mask(digit_rows[tid], score, tid, 10, 6, false);
+  const int x0 = alien_x[0], y0 = alien_y[0];
   // alien sprite rows, bit dx = column dx: .X..X. / ..XX.. / .XXXX. / XX..XX / XXXXXX / .X..X. (:413-435)
   const uint64_t sprite = 0x12ull | (0x0Cull << 6) | (0x1Eull << 12) | (0x33ull << 18) | (0x3Full << 24) | (0x12ull << 30);
   // cannon rows ...XX... / ..XXXX.. / ..XXXX.. / .XXXXXX. / XXXXXXXX x2 (:437-459)
@@ -296,7 +297,10 @@ __global__ void __launch_bounds__(kBlock) invaders_raster_kernel(StepArgs a, uin
   if (tid < kScreenH) {
     const int y = tid;
     uint32_t f = 0;
-    if (y >= y0 - 1 && y < y_end + 1) f |= kLayerAliens;
+    // a row of the formation that still holds an alien and whose sprites cover y
+#pragma unroll
+    for (int row = 0; row < si::kRows; row++)
+      if ((unsigned)(y - alien_y[row]) < 6u && ((aliens >> (row * si::kCols)) & ((1ull << si::kCols) - 1ull)) != 0ull) f |= kLayerAliens;
     if ((unsigned)(y - (kScreenH - 40)) < 6u) f |= kLayerCannon;
 #pragma unroll
     for (int b = 0; b < si::kMaxPB; b++)
@@ -310,94 +314,97 @@ __global__ void __launch_bounds__(kBlock) invaders_raster_kernel(StepArgs a, uin
   }
   __syncthreads();
 
-  uint8_t* frame = frames + env * (uint64_t)kFrameBytes;
-  // group c = y * 40 + g; a workgroup step of 256 groups is six rows and sixteen groups
-  int y = tid / kGroupsPerRow, g = tid - y * kGroupsPerRow;
-  for (int c = tid; c < kGroupsPerFrame; c += kBlock, y += 6, g += 16) {
-    if (g >= kGroupsPerRow) { g -= kGroupsPerRow; y += 1; }
+  // One 16-byte chunk per lane and iteration (gx_frame.h: the bytes of the six pixels p0 .. p0 + 5 of a row).
+  // Per layer a lane builds the 6-bit mask of the window's pixels the layer paints, spreads it to byte
+  // masks and lets the layer's colour replace what earlier layers left there.
+  constexpr int kChunksPerRow = kScreenW * 3 / 16, kChunks = kFrameBytes / 16;
+  uint4* frame = reinterpret_cast<uint4*>(frames + env * (uint64_t)kFrameBytes);
+  for (int c = tid; c < kChunks; c += kBlock) {
+    const int y = c / kChunksPerRow, j = c - y * kChunksPerRow;
     const uint32_t layers = row_layers[y];
-    if (layers == 0u) {
-      *reinterpret_cast<U3*>(frame + (uint64_t)c * 12) = U3{0u, 0u, 0u};
-      continue;
-    }
-    const int xg = 4 * g;
-    uint32_t idx[4] = {kBlack, kBlack, kBlack, kBlack};
-    // aliens, :361-385.  Row origins are 9..11 apart and a sprite is 6 tall, so the row whose
-    // sprite can cover y is floor((y - y0 + 1) / 10); the same with 12 and 6 for columns.
-    if (layers & kLayerAliens) {
-      int row = ((y - y0 + 1) * 205) >> 11;  // / 10, exact below 1024
-      row = row > si::kRows - 1 ? si::kRows - 1 : (row < 0 ? 0 : row);
-      const int dy = y - alien_y[row];
-      if ((unsigned)dy < 6u) {
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (layers != 0u) {
+      const int p0 = (16 * j) / 3, ph = j % 3;
+      const uint32_t sh8 = 8u * (uint32_t)ph;
+      // mask: bit q set = pixel p0 + q takes the colour rgb (r | g << 8 | b << 16)
+      auto paint = [&](uint32_t mask, uint32_t rgb) {
+        if (mask == 0u) return;
+        const uint4 e = expand_white6(mask, ph);
+        const uint32_t w0 = rgb | (rgb << 24), w1 = (rgb >> 8) | (rgb << 16), w2 = (rgb >> 16) | (rgb << 8);
+        const uint32_t c0 = __builtin_amdgcn_alignbit(w1, w0, sh8), c1 = __builtin_amdgcn_alignbit(w2, w1, sh8);
+        const uint32_t c2 = __builtin_amdgcn_alignbit(w0, w2, sh8);
+        v.x = (v.x & ~e.x) | (e.x & c0); v.y = (v.y & ~e.y) | (e.y & c1);
+        v.z = (v.z & ~e.z) | (e.z & c2); v.w = (v.w & ~e.w) | (e.w & c0);
+      };
+      // `bits`, a sprite row whose bit 0 is the pixel at x = left, as seen by the window
+      auto window = [&](uint32_t bits, int left) -> uint32_t {
+        const int sh = left - p0;
+        return sh >= 6 || sh <= -32 ? 0u : (sh >= 0 ? bits << sh : bits >> -sh) & 63u;
+      };
+      // aliens, :361-385.  Row origins are 9..11 apart and a sprite is 6 tall, so the row whose sprite can cover
+      // y is floor((y - y0 + 1) / 10); columns are 11..13 apart and 6 wide, so a sprite that meets the window
+      // covers its first or its last pixel, and the column of a pixel x is floor((x - x0 + 1) / 12).
+      if (layers & kLayerAliens) {
+        int row = ((y - y0 + 1) * 205) >> 11;  // / 10, exact below 1024
+        row = row > si::kRows - 1 ? si::kRows - 1 : (row < 0 ? 0 : row);
+        const int dy = y - alien_y[row];
+        if ((unsigned)dy < 6u) {
+          const uint32_t bits = (uint32_t)(sprite >> (6 * dy)) & 63u;
+          uint32_t m = 0;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const int d = xg + i - x0 + 1;
-          if (d >= 0) {
-            const int col = (d * 171) >> 11;  // / 12, exact below 512 (d <= 161 + |x0|; larger columns do not exist)
-            if (d < 512 && col < si::kCols) {
-              const int dx = xg + i - alien_x[col];
-              const int cell = row * si::kCols + col;
-              if ((unsigned)dx < 6u && ((aliens >> cell) & 1ull) && ((sprite >> (6 * dy + dx)) & 1ull))
-                idx[i] = kMagenta + (uint32_t)row;  // magenta, cyan, yellow, green, red
+          for (int end = 0; end < 2; end++) {
+            const int d = p0 + 5 * end - x0 + 1;
+            if (d >= 0 && d < 512) {
+              const int col = (d * 171) >> 11;  // / 12, exact below 512
+              if (col < si::kCols && ((aliens >> (row * si::kCols + col)) & 1ull)) m |= window(bits, alien_x[col]);
             }
           }
+          paint(m, palette(kMagenta + (uint32_t)row));  // magenta, cyan, yellow, green, red
         }
       }
-    }
-    // player cannon at ((int)playerX, 170), :388
-    if (layers & kLayerCannon) {
-      const int dy = y - (kScreenH - 40);
+      // player cannon at ((int)playerX, 170), :388
+      if (layers & kLayerCannon) paint(window((uint32_t)(cannon >> (8 * (y - (kScreenH - 40)))) & 0xFFu, player_x), palette(kGreen));
+      // player bullets (yellow) then alien bullets (red), 2 x 4 pixels each, :391-400
+      if (layers & kLayerPlayerBullets) {
+        uint32_t m = 0;
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int dx = xg + i - player_x;
-        if ((unsigned)dx < 8u && ((cannon >> (8 * dy + dx)) & 1ull)) idx[i] = kGreen;
+        for (int b = 0; b < si::kMaxPB; b++)
+          if (b < npb && (unsigned)(y - pby[b]) < 4u) m |= span_bits6(pbx[b], 2, p0);
+        paint(m, palette(kYellow));
       }
-    }
-    // player bullets (yellow) then alien bullets (red), 2 x 4 pixels each, :391-400
-    if (layers & kLayerPlayerBullets) {
+      if (layers & kLayerAlienBullets) {
+        uint32_t m = 0;
 #pragma unroll
-      for (int b = 0; b < si::kMaxPB; b++)
-        if (b < npb && (unsigned)(y - pby[b]) < 4u) {
-#pragma unroll
-          for (int i = 0; i < 4; i++)
-            if ((unsigned)(xg + i - pbx[b]) < 2u) idx[i] = kYellow;
-        }
-    }
-    if (layers & kLayerAlienBullets) {
-#pragma unroll
-      for (int b = 0; b < si::kMaxAB; b++)
-        if (b < nab && (unsigned)(y - aby[b]) < 4u) {
-#pragma unroll
-          for (int i = 0; i < 4; i++)
-            if ((unsigned)(xg + i - abx[b]) < 2u) idx[i] = kRed;
-        }
-    }
-    if (layers & kLayerHud) {
-      const int dy = y - 10;
-      // score (white), :403
-      if (dy < 5) {
-        const uint32_t m = (digit_rows[dy][g >> 3] >> (4 * (g & 7))) & 0xFu;
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-          if ((m >> i) & 1u) idx[i] = kWhite;
+        for (int b = 0; b < si::kMaxAB; b++)
+          if (b < nab && (unsigned)(y - aby[b]) < 4u) m |= span_bits6(abx[b], 2, p0);
+        paint(m, palette(kRed));
       }
-      // lives (green cannons), :404, 489-495: cannon k covers x in [120 - 10 k, 127 - 10 k]
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int u = (kScreenW - 40) + 7 - (xg + i);
-        if (u >= 0) {
-          const int k = (u * 205) >> 11;  // / 10
-          const int dx = 7 - (u - 10 * k);
-          if (dx >= 0 && k < shown && ((cannon >> (8 * dy + dx)) & 1ull)) idx[i] = kGreen;
+      if (layers & kLayerHud) {
+        const int dy = y - 10;
+        // score (white), :403
+        if (dy < 5) {
+          const uint32_t* dr = digit_rows[dy];
+          const uint64_t win = (uint64_t)dr[p0 >> 5] | ((uint64_t)dr[(p0 >> 5) + 1] << 32);
+          paint((uint32_t)(win >> (p0 & 31)) & 63u, palette(kWhite));
         }
+        // lives (green cannons), :404, 489-495: cannon k covers x in [120 - 10 k, 127 - 10 k]; 8 wide and 10
+        // apart, so one that meets the window covers its first or its last pixel
+        const uint32_t bits = (uint32_t)(cannon >> (8 * dy)) & 0xFFu;
+        uint32_t m = 0;
+#pragma unroll
+        for (int end = 0; end < 2; end++) {
+          const int u = (kScreenW - 40) + 7 - (p0 + 5 * end);
+          if (u >= 0) {
+            const int k = (u * 205) >> 11;  // / 10
+            if (k < shown) m |= window(bits, (kScreenW - 40) - 10 * k);
+          }
+        }
+        paint(m, palette(kGreen));
       }
+      // ground line, :407-410
+      if (layers & kLayerGround) paint(63u, palette(kGreen));
     }
-    // ground line, :407-410
-    if (layers & kLayerGround) idx[0] = idx[1] = idx[2] = idx[3] = kGreen;
-
-    U3 v{0u, 0u, 0u};
-    if ((idx[0] | idx[1] | idx[2] | idx[3]) != 0u) v = pack_rgb4(palette(idx[0]), palette(idx[1]), palette(idx[2]), palette(idx[3]));
-    *reinterpret_cast<U3*>(frame + (uint64_t)c * 12) = v;
+    frame[c] = v;
   }
 }
 
