@@ -8,7 +8,8 @@
 // (Envs.Breakout.cs:229-304).  Everything painted after the bricks is white,
 // so the final colour of a pixel is: white if any white object covers it,
 // else the colour of the brick row covering it, else black -- a pure function
-// of the pixel position and the state, evaluated four pixels per lane.
+// of the pixel position and the state, evaluated per 16-byte chunk (six pixels)
+// as two bit masks, white and brick.
 #pragma clang fp contract(off)
 
 #include <cstdio>

@@ -1,7 +1,8 @@
 // SpaceInvaders: game state stepped one env per lane in binary64, and the
-// 210x160x3 frame of every env written by a workgroup, each lane deciding four
-// pixels at a time from the game state (the layers applied in the reference's
-// own drawing order) and storing them as twelve coalesced bytes.
+// 210x160x3 frame of every env written by a workgroup, each lane deciding the
+// sixteen bytes of a chunk (six pixels) at a time from the game state: every
+// layer present in the row gives a 6-bit mask of the pixels it paints, applied
+// in the reference's own drawing order.
 //
 // The reference keeps its bullets in List<(double,double)>
 // (Envs.SpaceInvaders.cs:35-36).  Player bullets are capped at three by the
