@@ -53,3 +53,11 @@ def test_plain_launch_with_two_ranks():
     # whole-job value: both ranks' envs over the slowest rank's time
     assert abs(j["value"] - 2 * 262144 * 5 / (j["ms_per_step"] * 5e-3)) / j["value"] < 1e-6
     assert j["episode_stats"]["episodes"] >= 0  # six steps: no CartPole episode is over yet
+
+
+@pytest.mark.gpu
+def test_rccl_path_with_one_rank():
+    """the code a multi-GPU run takes -- process group over RCCL bound to the rank's device, barriers around the timed
+    region, max-over-ranks of the time -- with a world of one"""
+    j = _run("--force-dist", "--num-envs", "262144", "--no-extra", "--no-cpu-baseline")
+    assert j["n_gpus"] == 1 and j["value"] > 0
