@@ -64,6 +64,9 @@ struct gx_vec {
   int block = 256;  // threads per workgroup of this batch's step kernels
   bool is_classic = false, is_tabular = false, is_frame = false, is_acrobot64 = false;  // is_frame: Pong, Breakout, SpaceInvaders
   bool is_classic64 = false;  // GX_MODE_FP64 on one of the five classic-control envs
+  // Acrobot in EXACT mode: two more real rows (the angles) behind the six of the state image, see AcrobotAngles
+  bool acrobot_angles = false;
+  int classic_id = 0;  // what the classic-control launchers take: the env id, or kEnvAcrobotAngles
   bool is_blackjack = false;  // int-state env like the tabular ones (is_tabular is set too), with kernels of its own
   bool ep_return_f64 = false;
   // device memory
@@ -506,7 +509,7 @@ int launch_step(gx_vec* v, const void* d_actions, int k_steps, uint64_t action_s
   const bool bounded = (v->desc.flags & GX_AUTORESET) && !v->state_dirty;
   if (v->is_acrobot64) e = launch_acrobot64_step(a, policy, fused, v->grid, stream);
   else if (v->is_classic64) e = launch_classic64_step(v->desc.env_id, a, policy, fused, bounded, v->grid, stream);
-  else if (v->is_classic) e = launch_classic_step(v->desc.env_id, a, v->desc.mode, policy, fused, bounded, v->grid, stream);
+  else if (v->is_classic) e = launch_classic_step(v->classic_id, a, v->desc.mode, policy, fused, bounded, v->grid, stream);
   else if (v->is_blackjack) e = launch_blackjack_step(a, policy, v->grid, stream);
   else if (v->is_tabular) e = launch_tabular_step(v->desc.env_id, a, policy, v->grid, v->block, v->table_lds_bytes, stream);
   else {
@@ -530,7 +533,7 @@ int launch_sample(gx_vec* v, uint64_t tick, void* d_out, hipStream_t stream) {
   hipError_t e;
   if (v->is_acrobot64) e = launch_acrobot64_sample(a, d_out, grid, stream);
   else if (v->is_classic64) e = launch_classic64_sample(v->desc.env_id, a, d_out, grid, stream);
-  else if (v->is_classic) e = launch_classic_sample(v->desc.env_id, a, d_out, grid, stream);
+  else if (v->is_classic) e = launch_classic_sample(v->classic_id, a, d_out, grid, stream);
   else if (v->is_blackjack) e = launch_blackjack_sample(a, d_out, grid, stream);
   else if (v->is_tabular) e = launch_tabular_sample(v->desc.env_id, a, d_out, grid, stream);
   else if (v->desc.env_id == GX_ENV_PONG) e = launch_pong_sample(a, d_out, grid, stream);
@@ -597,6 +600,11 @@ extern "C" int gx_vec_create(gx_ctx* ctx, const gx_desc* desc, gx_vec** out) {
   v->is_acrobot64 = env == GX_ENV_ACROBOT && (desc->flags & GX_ACROBOT_RK4);
   v->is_classic = env <= GX_ENV_ACROBOT;
   v->is_classic64 = v->is_classic && !v->is_acrobot64 && desc->mode == GX_MODE_FP64;
+  v->acrobot_angles = env == GX_ENV_ACROBOT && !v->is_acrobot64 && desc->mode == GX_MODE_EXACT;
+  if (const char* s = std::getenv("GYMX_ACROBOT_ANGLES")) {  // tuning aid: 0 = the six-row form
+    if (std::atoi(s) == 0) v->acrobot_angles = false;
+  }
+  v->classic_id = v->acrobot_angles ? kEnvAcrobotAngles : env;
   v->is_blackjack = env == GX_ENV_BLACKJACK;
   v->is_tabular = env == GX_ENV_FROZENLAKE || env == GX_ENV_TAXI || env == GX_ENV_CLIFFWALKING || env == GX_ENV_DUMMY || v->is_blackjack;
   v->is_frame = env == GX_ENV_PONG || env == GX_ENV_BREAKOUT || env == GX_ENV_SPACEINVADERS;
@@ -627,7 +635,8 @@ extern "C" int gx_vec_create(gx_ctx* ctx, const gx_desc* desc, gx_vec** out) {
 
   const gx_info& in = v->info;
   const size_t rsz = dtype_size(in.real_dtype);
-  if (in.n_real) VEC_TRY(hipMalloc(&v->d_real, (size_t)in.n_real * v->stride * rsz));
+  const size_t real_rows = (size_t)in.n_real + (v->acrobot_angles ? 2 : 0);
+  if (in.n_real) VEC_TRY(hipMalloc(&v->d_real, real_rows * v->stride * rsz));
   VEC_TRY(hipMalloc((void**)&v->d_int, (size_t)in.n_int * v->stride * 4));
   VEC_TRY(hipMalloc(&v->d_reward, v->stride * dtype_size(in.reward_dtype)));
   VEC_TRY(hipMalloc((void**)&v->d_done, v->stride));
@@ -638,7 +647,7 @@ extern "C" int gx_vec_create(gx_ctx* ctx, const gx_desc* desc, gx_vec** out) {
   VEC_TRY(hipHostMalloc((void**)&v->h_error, 64, hipHostMallocDefault));
   VEC_TRY(hipHostMalloc((void**)&v->h_stat, sizeof(StatSlot), hipHostMallocDefault));
   *v->h_error = 0;
-  if (in.n_real) VEC_TRY(hipMemset(v->d_real, 0, (size_t)in.n_real * v->stride * rsz));
+  if (in.n_real) VEC_TRY(hipMemset(v->d_real, 0, real_rows * v->stride * rsz));
   VEC_TRY(hipMemset(v->d_int, 0, (size_t)in.n_int * v->stride * 4));
   VEC_TRY(hipMemset(v->d_reward, 0, v->stride * dtype_size(in.reward_dtype)));
   VEC_TRY(hipMemset(v->d_done, 0, v->stride));
@@ -760,7 +769,7 @@ extern "C" int gx_vec_reset(gx_vec* v) {
   hipError_t e;
   if (v->is_acrobot64) e = launch_acrobot64_reset(a, 0, v->grid, c->compute);
   else if (v->is_classic64) e = launch_classic64_reset(v->desc.env_id, a, v->grid, c->compute);
-  else if (v->is_classic) e = launch_classic_reset(v->desc.env_id, a, v->grid, c->compute);
+  else if (v->is_classic) e = launch_classic_reset(v->classic_id, a, v->grid, c->compute);
   else if (v->is_blackjack) e = launch_blackjack_reset(a, v->grid, c->compute);
   else if (v->is_tabular) e = launch_tabular_reset(v->desc.env_id, a, v->grid, c->compute);
   else {
@@ -828,6 +837,7 @@ extern "C" int gx_vec_set_state(gx_vec* v, const void* host, size_t bytes) {
   StepArgs a = make_args(v, nullptr, 1, 0);
   if (v->is_frame) HIP_TRY(frame_raster(v, a, c->compute));
   if (v->is_acrobot64) HIP_TRY(launch_acrobot64_reset(a, 1, v->grid, c->compute));
+  if (v->acrobot_angles) HIP_TRY(launch_classic_derive(v->classic_id, a, v->grid, c->compute));
   HIP_TRY(hipStreamSynchronize(c->compute));
   return GX_OK;
 }

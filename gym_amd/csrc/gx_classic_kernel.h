@@ -147,10 +147,51 @@ struct RegState<E, std::void_t<decltype(E::NR)>> {
   static constexpr int value = E::NR;
 };
 
-// minimum resident waves per SIMD the fused kernels are compiled for (caps their registers)
+// Leading rows of an env that its step never reads: it rewrites them from the others (E::kWriteOnlyRows).
+// They are not loaded and go out past the caches like the result rows.
+template <class E, class = void>
+struct WriteOnlyRows {
+  static constexpr int value = 0;
+};
+template <class E>
+struct WriteOnlyRows<E, std::void_t<decltype(E::kWriteOnlyRows)>> {
+  static constexpr int value = E::kWriteOnlyRows;
+};
+
+template <class E, class = void>
+struct RecomputeAddresses {
+  static constexpr bool value = false;
+};
+template <class E>
+struct RecomputeAddresses<E, std::void_t<decltype(E::kRecomputeAddresses)>> {
+  static constexpr bool value = E::kRecomputeAddresses;
+};
+
+// E::kStateInLds: between its load and its store the real state of a lane's W envs lives in LDS
+// ([row][env of the lane][lane], one dword per lane: conflict-free), and only the env being stepped is in
+// registers -- for an env whose arithmetic needs most of the register file for itself.  A wave touches only its
+// own lanes' words, so no barrier is involved.
+template <class E, class = void>
+struct StateInLds {
+  static constexpr bool value = false;
+};
+template <class E>
+struct StateInLds<E, std::void_t<decltype(E::kStateInLds)>> {
+  static constexpr bool value = E::kStateInLds;
+};
+
+// minimum resident waves per SIMD the fused kernels are compiled for (caps their registers): E::kMinWaves, else 1
 #ifndef GX_FUSED_MIN_WAVES
 #define GX_FUSED_MIN_WAVES 1
 #endif
+template <class E, class = void>
+struct MinWaves {
+  static constexpr int value = GX_FUSED_MIN_WAVES;
+};
+template <class E>
+struct MinWaves<E, std::void_t<decltype(E::kMinWaves)>> {
+  static constexpr int value = E::kMinWaves;
+};
 
 // CACHED (fused K-step rollouts with the random policy): the policy block of four ticks is kept
 // in registers, so the generator runs once every four steps; the single-step kernels draw
@@ -160,7 +201,7 @@ struct RegState<E, std::void_t<decltype(E::NR)>> {
 // the plain kernels registers (the scalar file is full: they spill into vector registers) and with
 // them a resident wave.
 template <class E, int MODE, int POLICY, bool FUSED, bool BOUNDED, bool CACHED = false, bool ROWS = false>
-__global__ void __launch_bounds__(kClassicBlock, (FUSED && BOUNDED) ? GX_FUSED_MIN_WAVES : 1) classic_step_kernel(StepArgs a) {
+__global__ void __launch_bounds__(kClassicBlock, (FUSED && BOUNDED) ? MinWaves<E>::value : 1) classic_step_kernel(StepArgs a) {
   using Real = typename E::Real;
   using Act = typename E::Act;
   using Rew = typename E::Rew;
@@ -168,6 +209,11 @@ __global__ void __launch_bounds__(kClassicBlock, (FUSED && BOUNDED) ? GX_FUSED_M
   constexpr int NS = E::NS;
   constexpr int NR = RegState<E>::value;
   constexpr int W = E::W;
+  constexpr int WO = WriteOnlyRows<E>::value;
+  constexpr bool PARK = StateInLds<E>::value;
+  static_assert(!PARK || (NR == NS && !E::kDerivedObs), "the LDS form holds the stored rows only");
+  __shared__ Real parked[PARK ? NS : 1][W][kClassicBlock];
+  const int lane = threadIdx.x;
 
   const bool autoreset = FUSED ? true : (a.flags & GX_AUTORESET) != 0;
   const bool record = FUSED ? true : (a.flags & GX_RECORD_STATS) != 0;
@@ -197,10 +243,16 @@ __global__ void __launch_bounds__(kClassicBlock, (FUSED && BOUNDED) ? GX_FUSED_M
     int32_t ep_len[W] = {};
 #pragma unroll
     for (int c = 0; c < NS; c++) {
-      Real v[W];
-      load_row<Real, W>(sreal + (uint64_t)c * a.stride, q, v);
+      Real v[W] = {};
+      if (c >= WO) load_row<Real, W>(sreal + (uint64_t)c * a.stride, q, v);
 #pragma unroll
-      for (int j = 0; j < W; j++) s[j][c] = v[j];
+      for (int j = 0; j < W; j++) {
+        if constexpr (PARK) {
+          if (c >= WO) parked[c][j][lane] = v[j];
+        } else {
+          s[j][c] = v[j];
+        }
+      }
     }
     if constexpr (NR > NS) {
 #pragma unroll
@@ -243,7 +295,16 @@ __global__ void __launch_bounds__(kClassicBlock, (FUSED && BOUNDED) ? GX_FUSED_M
         // per env would split their arithmetic into separate blocks)
         if (E::kCheckAction && POLICY == GX_POLICY_DEVICE_ACTIONS) bad_action |= !E::action_valid(act[j]) && q * W + j < a.num_envs;
         bool d;
-        E::template step<MODE, BOUNDED>(s[j], steps[j], act[j], reward[j], d);
+        if constexpr (PARK) {
+          Real cur[NR] = {};
+#pragma unroll
+          for (int c = WO; c < NS; c++) cur[c] = parked[c][j][lane];
+          E::template step<MODE, BOUNDED>(cur, steps[j], act[j], reward[j], d);
+#pragma unroll
+          for (int c = 0; c < NS; c++) parked[c][j][lane] = cur[c];
+        } else {
+          E::template step<MODE, BOUNDED>(s[j], steps[j], act[j], reward[j], d);
+        }
         // Wrappers.TimeLimit.cs:26-31; its counter always equals the env's own
         bool t = time_limit > 0 && steps[j] >= time_limit;
         d = d || t;
@@ -281,11 +342,17 @@ __global__ void __launch_bounds__(kClassicBlock, (FUSED && BOUNDED) ? GX_FUSED_M
             const int jj = __ffs((int)pending) - 1;
             Real fresh[NR];
             E::reset(fresh, key, env0 + (uint64_t)jj);
+            if constexpr (PARK) {
+#pragma unroll
+              for (int c = 0; c < NS; c++) parked[c][jj][lane] = fresh[c];
+            }
 #pragma unroll
             for (int j = 0; j < W; j++) {
               if (jj == j) {
+                if constexpr (!PARK) {
 #pragma unroll
-                for (int c = 0; c < NR; c++) s[j][c] = fresh[c];
+                  for (int c = 0; c < NR; c++) s[j][c] = fresh[c];
+                }
                 steps[j] = 0;
               }
             }
@@ -295,23 +362,28 @@ __global__ void __launch_bounds__(kClassicBlock, (FUSED && BOUNDED) ? GX_FUSED_M
       }
     }
 
+    // E::kRecomputeAddresses: the stores form their addresses from the group index again instead of keeping the
+    // loads' address pairs (two registers per row) alive through the arithmetic
+    uint64_t qs = q;
+    if constexpr (RecomputeAddresses<E>::value) asm("" : "+v"(qs));
 #pragma unroll
     for (int c = 0; c < NS; c++) {
       Real v[W];
 #pragma unroll
-      for (int j = 0; j < W; j++) v[j] = s[j][c];
-      store_row<Real, W>(sreal + (uint64_t)c * a.stride, q, v);
+      for (int j = 0; j < W; j++) v[j] = PARK ? parked[c][j][lane] : s[j][c];
+      if (c >= WO) store_row<Real, W>(sreal + (uint64_t)c * a.stride, qs, v);
+      else store_row_nt<Real, W>(sreal + (uint64_t)c * a.stride, qs, v);
     }
-    store_row<int32_t, W>(steps_row, q, steps);
+    store_row<int32_t, W>(steps_row, qs, steps);
     if (record) {
-      if (!derive_returns) store_row<EpRet, W>(static_cast<EpRet*>(a.ep_return), q, ep_ret);
-      if (ep_length_row) store_row<int32_t, W>(ep_length_row, q, ep_len);
+      if (!derive_returns) store_row<EpRet, W>(static_cast<EpRet*>(a.ep_return), qs, ep_ret);
+      if (ep_length_row) store_row<int32_t, W>(ep_length_row, qs, ep_len);
     }
     // write-only rows: streamed past the caches, which stay with the rows the next step re-reads
     if (!ROWS || !a.skip_last) {
-      store_row_nt<Rew, W>(static_cast<Rew*>(a.reward), q, reward);
-      store_flags_nt<W>(a.done, q, done);
-      if (truncated_row) store_flags_nt<W>(truncated_row, q, trunc);
+      store_row_nt<Rew, W>(static_cast<Rew*>(a.reward), qs, reward);
+      store_flags_nt<W>(a.done, qs, done);
+      if (truncated_row) store_flags_nt<W>(truncated_row, qs, trunc);
     }
     if constexpr (E::kDerivedObs) {
       float o[W][E::NOBS];
@@ -381,6 +453,36 @@ __global__ void __launch_bounds__(kClassicBlock) classic_reset_kernel(StepArgs a
         for (int j = 0; j < W; j++) v[j] = o[j][c];
         store_row<float, W>(a.obs + (uint64_t)c * a.stride, q, v);
       }
+    }
+  }
+}
+
+// The rows behind the state image (E::kImageRows .. E::NS) from the rows of the image, after the image was
+// written from outside.
+template <class E>
+__global__ void __launch_bounds__(kClassicBlock) classic_derive_kernel(StepArgs a) {
+  using Real = typename E::Real;
+  constexpr int NS = E::NS;
+  constexpr int W = E::W;
+  Real* const sreal = static_cast<Real*>(a.state_real);
+  const uint64_t ngroups = (a.num_envs + (W - 1)) / W;
+  for (uint64_t q = (uint64_t)blockIdx.x * kClassicBlock + threadIdx.x; q < ngroups; q += (uint64_t)gridDim.x * kClassicBlock) {
+    Real s[W][NS];
+#pragma unroll
+    for (int c = 0; c < NS; c++) {
+      Real v[W] = {};
+      if (c < E::kImageRows) load_row<Real, W>(sreal + (uint64_t)c * a.stride, q, v);
+#pragma unroll
+      for (int j = 0; j < W; j++) s[j][c] = v[j];
+    }
+#pragma unroll
+    for (int j = 0; j < W; j++) E::derive(s[j]);
+#pragma unroll
+    for (int c = E::kImageRows; c < NS; c++) {
+      Real v[W];
+#pragma unroll
+      for (int j = 0; j < W; j++) v[j] = s[j][c];
+      store_row<Real, W>(sreal + (uint64_t)c * a.stride, q, v);
     }
   }
 }

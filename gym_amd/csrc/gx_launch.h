@@ -10,10 +10,15 @@ namespace gx {
 // classic control (gx_classic.hip)
 // fused: auto-reset + RecordEpisodeStatistics on and no TimeLimit; bounded: the env's angle
 // invariants hold for the current state (see gx_classic_kernel.h)
+// env_id: a GX_ENV_* of the five, or kEnvAcrobotAngles -- Acrobot in EXACT mode on rows the library owns, which
+// has two more real rows (the angles) behind the six of the state image
+constexpr int kEnvAcrobotAngles = 1000;
 hipError_t launch_classic_step(int env_id, const StepArgs& a, int mode, int policy, bool fused, bool bounded, dim3 grid,
                                hipStream_t stream);
 hipError_t launch_classic_reset(int env_id, const StepArgs& a, dim3 grid, hipStream_t stream);
 hipError_t launch_classic_sample(int env_id, const StepArgs& a, void* out, dim3 grid, hipStream_t stream);
+// the derived rows from the rows of the state image, after the image was written from outside (kEnvAcrobotAngles only)
+hipError_t launch_classic_derive(int env_id, const StepArgs& a, dim3 grid, hipStream_t stream);
 
 // the same five envs in binary64, GX_MODE_FP64 (gx_classic64.hip)
 hipError_t launch_classic64_step(int env_id, const StepArgs& a, int policy, bool fused, bool bounded, dim3 grid,

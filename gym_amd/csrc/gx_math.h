@@ -214,6 +214,31 @@ GX_HD double atan2_f64(double y, double x) {
   return (x != x || y != y) ? x + y : a;
 }
 
+// (float)atan2((double)s, (double)c) for s = (float)S, c = (float)C with S = sin(theta), C = cos(theta) as
+// sincos_bounded returns them, |theta| < 1000: the angle a step that keeps (cos, sin) of an angle as floats
+// reads back from them.  The angle of (c, s) is theta brought into [-pi, pi] plus the small rotation the two
+// roundings cause: with es = s - S and ec = c - C (exact in binary64),
+//   atan2(s, c) = w + atan2(s C - c S, c C + s S) = w + (es C - ec S) / (1 + ec C + es S)
+// up to terms below 2^-70, where the quotient is below 2^-23, so 1 / (1 + h) = 1 - h is enough and the arc
+// tangent is its argument.  The errors of S and C (a unit in their last place) enter scaled by the other
+// one, i.e. by at most the size of the result: the sum is within about two units in the last place of the
+// binary64 angle, like atan2_f64, at a third of its cost.  The distance of a float to an odd multiple of pi
+// is above 1e-8 for |theta| < 16, far more than the rotation, so the sum cannot leave [-pi, pi].
+// The sign is that of s, as atan2 gives it (also for zeros).  NaN or infinite theta gives NaN.
+GX_HD float atan2_of_rounded_sincos(float theta, double S, double C, float s, float c) {
+  const double INV_2PI = 0x1.45f306dc9c883p-3;
+  const double TWO_PI_HI = 0x1.921fb54442d18p+2, TWO_PI_LO = 0x1.1a62633145c07p-52;
+  const double MAGIC = 0x1.8p+52;
+  const double x = (double)theta;
+  const double k = fma(x, INV_2PI, MAGIC) - MAGIC;       // whole turns, rounded to nearest
+  const double w = fma(-k, TWO_PI_LO, fma(-k, TWO_PI_HI, x));
+  const double es = (double)s - S, ec = (double)c - C;
+  const double num = fma(es, C, -(ec * S));
+  const double h = fma(es, S, ec * C);
+  const double a = w + fma(-num, h, num);
+  return copysignf((float)a, s);
+}
+
 // ---- binary32 routines of the FAST32 mode (held to 1e-5 relative, not to the last bit) ----
 
 // sin(x) and cos(x) in binary32 for |x| up to a few thousand, absolute error about 1e-7:

@@ -5,6 +5,7 @@
 //                 [-pi/4, pi/4] against (float)sin((double)x), (float)cos(...)
 //   sincos_bounded: floats in [-16, 16] and their shifts by -pi/2 and +pi, the same way
 //   atan2_f64: random float pairs against (float)atan2((double)y, (double)x), and in binary64
+//   atan2_of_rounded_sincos: floats in [-16, 16] against (float)atan2 of the rounded sine and cosine
 //   div_by_rcp: floats over every divisor of [2.5, 4.5] and [0.5, 1.25] against a / b
 //   div_by_total_mass: every `stride`-th float in [2^-100, 2^100], both signs,
 //                 against x / 1.1f
@@ -122,6 +123,24 @@ int main(int argc, char** argv) {
   }
   std::printf("atan2_f64: %llu float pairs, mismatches after rounding to float %llu, worst error %.3f ulp, special values %s\n", na, bad_a,
               worst_ulp, special_ok ? "ok" : "WRONG");
+  // ---- atan2_of_rounded_sincos: the angle read back from the float roundings of sin and cos, for the
+  // angles one Acrobot step can produce (|theta| <= pi + 0.2 * 9 pi < 9) and beyond, against atan2 of the pair
+  unsigned long long nr = 0, bad_r = 0;
+  for (uint32_t sign = 0; sign < 2; sign++)
+    for (uint32_t b = 0; b <= hi16; b += stride / 4 + 1) {
+      const float th = from_bits(b | (sign << 31));
+      double S, C;
+      gx::math::sincos_bounded((double)th, S, C);
+      const float s = (float)S, c = (float)C;
+      const float got = gx::math::atan2_of_rounded_sincos(th, S, C, s, c);
+      const float ref = (float)std::atan2((double)s, (double)c);
+      nr++;
+      if (to_bits(got) != to_bits(ref)) {
+        bad_r++;
+        if (bad_r <= 5) std::printf("atan2_of_rounded_sincos(%.9g): %.9g, libm %.9g\n", th, got, ref);
+      }
+    }
+  std::printf("atan2_of_rounded_sincos: %llu angles, mismatches %llu\n", nr, bad_r);
   // ---- division through a binary64 reciprocal: every divisor of the two ranges the Acrobot step has
   // (stepping through them), dividends of every magnitude including those with subnormal quotients, and
   // the reciprocal pushed two units in the last place either way (the device's Newton reciprocal is not
@@ -164,6 +183,6 @@ int main(int argc, char** argv) {
     }
   std::printf("div_by_total_mass: %llu inputs, mismatches %llu\n", nd, bad_d);
   // one rounding-boundary event per ~2^28 trig calls is expected; the division must be exact
-  const bool ok = special_ok && worst_ulp <= 2.0 && bad_a * (1ull << 23) <= na + (1ull << 23) && worst < 1e-15 && worst_f < 3e-7 && worst_at < 6e-7 && bad_d == 0 && bad_q == 0 && bad_b * (1ull << 24) <= nb + (1ull << 24) && bad_s * (1ull << 24) <= n + (1ull << 24) && bad_c * (1ull << 24) <= n + (1ull << 24);
+  const bool ok = special_ok && bad_r * (1ull << 23) <= nr + (1ull << 23) && worst_ulp <= 2.0 && bad_a * (1ull << 23) <= na + (1ull << 23) && worst < 1e-15 && worst_f < 3e-7 && worst_at < 6e-7 && bad_d == 0 && bad_q == 0 && bad_b * (1ull << 24) <= nb + (1ull << 24) && bad_s * (1ull << 24) <= n + (1ull << 24) && bad_c * (1ull << 24) <= n + (1ull << 24);
   return ok ? 0 : 1;
 }
