@@ -140,7 +140,9 @@ typedef struct gx_info {
 typedef struct gx_view {
   uint64_t num_envs;
   uint64_t stride;    /* elements between consecutive component arrays (>= num_envs) */
-  void* state_real;   /* [n_real][stride] float or double */
+  void* state_real;   /* [n_real][stride] float or double; for reading -- a state is written with gx_vec_set_state
+                         (Acrobot in GX_MODE_EXACT keeps two rows of derived angles behind these, which a write
+                         that bypasses gx_vec_set_state would leave stale) */
   int32_t* state_int; /* [n_int][stride] */
   void* obs;          /* classic: == state_real (or float [obs_dim][stride] when it is derived);
                          tabular: == state_int; Pong, Breakout, SpaceInvaders: uint8 [num_envs][100800] */
