@@ -26,6 +26,13 @@ __device__ __forceinline__ float div_total_mass(float x) {
 // follow the cited reference lines.  `steps` is the env's own `_steps` field.
 
 struct CartPole {
+  // the lane's four env states wait in LDS while one is stepped, and the stores form their addresses again: 89 -> 55
+  // registers, eight waves per SIMD instead of five.  The single step does not care (0.146 ms either way, it is
+  // not short of waves); the K = 64 rollout, which is arithmetic from end to end, gains 10 % (3.37 -> 3.03 ms).
+  // MountainCar, MountainCarContinuous and Pendulum lose 1-2 % on the single step with the same change and keep
+  // their states in registers.
+  static constexpr bool kStateInLds = true;
+  static constexpr bool kRecomputeAddresses = true;
   static constexpr int NS = 4;
   using Real = float;
   static constexpr int W = 4;
