@@ -227,7 +227,6 @@ __global__ void __launch_bounds__(kClassicBlock, (FUSED && BOUNDED) ? MinWaves<E
   // nor written (8 bytes per env-step less), the statistics come out the same.
   const bool derive_returns = FUSED && E::kStepReturn != kNoStepReturn && a.derive_returns != 0;
   constexpr bool kLdsStats = std::is_same<EpRet, int32_t>::value && POLICY == GX_POLICY_RANDOM;
-  static_assert(kClassicBlock == 64, "a lane's LDS statistics record is indexed by threadIdx.x");
   __shared__ LaneStatsLds lane_stats;
   ThreadStats<EpRet> acc;
   if (kLdsStats && record) lane_stats_init(lane_stats);

@@ -12,8 +12,13 @@ namespace gx {
 
 constexpr int kBlock = 256;          // threads per workgroup (4 waves)
 // The classic-control kernels run one wave per workgroup: measured on the CartPole step at
-// 16 Mi envs, 64 / 128 / 256 / 512 threads take 0.142 / 0.146 / 0.1465 / 0.150 ms.
-constexpr int kClassicBlock = 64;
+// 16 Mi envs, 64 / 128 / 256 / 512 threads take 0.142 / 0.146 / 0.1465 / 0.150 ms; with 128 or 256 threads
+// MountainCar, MountainCarContinuous and Pendulum gain 1-3 %, CartPole and Acrobot lose as much.
+// (-DGX_CLASSIC_BLOCK=n builds the other sizes for such comparisons.)
+#ifndef GX_CLASSIC_BLOCK
+#define GX_CLASSIC_BLOCK 64
+#endif
+constexpr int kClassicBlock = GX_CLASSIC_BLOCK;
 // The tabular step kernels stage the transition table in LDS once per workgroup, so their
 // workgroup size follows the table.  At 64 Mi envs, 256 / 128 threads: FrozenLake 4x4
 // (352 bytes) 0.283 / 0.271 ms, 8x8 (1.3 KB) 0.279 / 0.266 ms, slippery 8x8 (3.9 KB)
