@@ -10,12 +10,14 @@
 //  - the reference's (Envs.Blackjack.cs:21-40): Reset draws Next(12,22), Next(1,11), Next(2)==1;
 //    Step leaves the state alone, ends the episode at the tenth step and pays 1 there;
 //  - GX_BLACKJACK_FULL, an extension: upstream Blackjack-v1 (natural = False, sab = False) with an
-//    infinite deck.  Reset deals the dealer's two cards, then the player's two (stream 0, draws
-//    0..3).  Hit (any non-zero action) takes the card from the env's word of the tick (stream 3):
-//    the base-13 digit after the action digit, the same construction as FrozenLake's slippery
-//    outcome.  Stick lets the dealer draw to 17 or more from stream 1 (draws 0, 1, ...) and pays
-//    the comparison of the two scores; the cards drawn are added to the face-down row, as
-//    upstream's dealer keeps them.
+//    infinite deck.  Its draws come from three words per env and tick, each word one of the four
+//    of a block that four consecutive envs share (one generator call per lane serves its four
+//    envs), successive cards being successive base-13 digits of the word (word_next_digit):
+//      stream 3  the action of the random policy (one binary digit), then the card of a hit;
+//      stream 5  the dealer's first four draws after a stick (to 17 or more; the cards are added
+//                to the face-down row, as upstream's dealer keeps them); a dealer who needs a
+//                fifth draw, one hand in a thousand, goes on with the env's own stream 1;
+//      stream 4  Reset: the dealer's two cards, then the player's two.
 #include "gx_device.h"
 #include "gx_launch.h"
 
@@ -43,20 +45,34 @@ __device__ __forceinline__ uint32_t pack4(const bool (&b)[4]) {
 __device__ __forceinline__ int32_t card_of(int32_t rank) { return rank + 1 < 10 ? rank + 1 : 10; }
 __device__ __forceinline__ int32_t hand_value(int32_t raw, bool ace) { return raw + ((ace && raw + 10 <= 21) ? 10 : 0); }
 
-template <bool FULL>
-__device__ __forceinline__ void blackjack_reset_one(const RngKey& key, uint64_t env, int32_t& obs, int32_t& hidden) {
+constexpr uint32_t kStreamDeal = 4, kStreamDealer = 5;
+
+// Envs.Blackjack.cs:23-25
+__device__ __forceinline__ void blackjack_reset_reference(const RngKey& key, uint64_t env, int32_t& obs, int32_t& hidden) {
   const Draws d = philox_block(key, env, 0, 0);
-  if (!FULL) {  // Envs.Blackjack.cs:23-25
-    const int32_t sum = 12 + d.below(0, 10), dealer = 1 + d.below(1, 10), usable = d.below(2, 2) == 1;
-    obs = (sum * 11 + dealer) * 2 + usable;
-    hidden = 0;
+  const int32_t sum = 12 + d.below(0, 10), dealer = 1 + d.below(1, 10), usable = d.below(2, 2) == 1;
+  obs = (sum * 11 + dealer) * 2 + usable;
+  hidden = 0;
+}
+// upstream's reset from the env's deal word
+__device__ __forceinline__ void blackjack_deal(uint32_t word, int32_t& obs, int32_t& hidden) {
+  const int32_t d0 = card_of(word_next_digit(word, 13)), d1 = card_of(word_next_digit(word, 13));
+  const int32_t p0 = card_of(word_next_digit(word, 13)), p1 = card_of(word_next_digit(word, 13));
+  const int32_t raw = p0 + p1;
+  const bool usable = (p0 == 1 || p1 == 1) && raw + 10 <= 21;
+  obs = ((raw + (usable ? 10 : 0)) * 11 + d0) * 2 + (usable ? 1 : 0);
+  hidden = d1 | ((d1 == 1) << 8);
+}
+// the words of a lane's four envs from a shared-block stream: one generator call when the first env opens a block
+template <bool ALIGNED>
+__device__ __forceinline__ void lane_words(const StepArgs& a, uint64_t tick, uint64_t env0, uint32_t stream, uint32_t (&word)[4]) {
+  if (ALIGNED) {
+    const Draws d = tabular_block(a.seed_lo, a.seed_hi, tick, env0 >> 2, stream);
+#pragma unroll
+    for (int j = 0; j < 4; j++) word[j] = d.w[j];
   } else {
-    const int32_t d0 = card_of(d.below(0, 13)), d1 = card_of(d.below(1, 13));
-    const int32_t p0 = card_of(d.below(2, 13)), p1 = card_of(d.below(3, 13));
-    const int32_t raw = p0 + p1;
-    const bool usable = (p0 == 1 || p1 == 1) && raw + 10 <= 21;
-    obs = ((raw + (usable ? 10 : 0)) * 11 + d0) * 2 + (usable ? 1 : 0);
-    hidden = d1 | ((d1 == 1) << 8);
+#pragma unroll
+    for (int j = 0; j < 4; j++) word[j] = tabular_word(a.seed_lo, a.seed_hi, tick, env0 + j, stream);
   }
 }
 
@@ -94,16 +110,12 @@ __global__ void __launch_bounds__(kBlock) blackjack_step_kernel(StepArgs a) {
       int32_t act[4] = {0, 0, 0, 0};
       if (POLICY == GX_POLICY_DEVICE_ACTIONS)
         load4i(static_cast<const int32_t*>(a.actions) + (uint64_t)k * a.action_stride, q, act);
-      uint32_t word[4] = {0, 0, 0, 0};
-      if (need_word) {
-        if (ALIGNED) {
-          const Draws d = tabular_block(a.seed_lo, a.seed_hi, tick, env0 >> 2);
-#pragma unroll
-          for (int j = 0; j < 4; j++) word[j] = d.w[j];
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; j++) word[j] = tabular_word(a.seed_lo, a.seed_hi, tick, env0 + j);
-        }
+      uint32_t word[4] = {0, 0, 0, 0}, dealer_word[4] = {0, 0, 0, 0}, deal_word[4] = {0, 0, 0, 0};
+      if (need_word) lane_words<ALIGNED>(a, tick, env0, 3, word);
+      if (FULL) {
+        // with four envs per lane nearly every lane has one that sticks and one that ends: both words always
+        lane_words<ALIGNED>(a, tick, env0, kStreamDealer, dealer_word);
+        if (autoreset) lane_words<ALIGNED>(a, tick, env0, kStreamDeal, deal_word);
       }
 #pragma unroll
       for (int j = 0; j < 4; j++) {
@@ -131,7 +143,19 @@ __global__ void __launch_bounds__(kBlock) blackjack_step_kernel(StepArgs a) {
             bool hace = ((hidden[j] >> 8) & 1) != 0;
             int32_t raw = dealer + hsum;
             bool ace = dealer == 1 || hace;
-            // four draws per generator call; an ace-and-deuce dealer can need a second call
+            // the first four draws are the digits of the env's dealer word
+            uint32_t dw = dealer_word[j];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+              const int32_t card = card_of(word_next_digit(dw, 13));
+              if (hand_value(raw, ace) < 17) {
+                raw += card;
+                hsum += card;
+                ace = ace || card == 1;
+                hace = hace || card == 1;
+              }
+            }
+            // a fifth and later draws (a hand of seven or more cards): the env's own stream 1, four draws per call
             for (uint32_t block = 0; hand_value(raw, ace) < 17; block++) {
               const Draws dd = philox_block(key, env, 1, block);
 #pragma unroll
@@ -165,7 +189,8 @@ __global__ void __launch_bounds__(kBlock) blackjack_step_kernel(StepArgs a) {
           ep_len[j] = d ? 0 : ep_len[j];
         }
         if (autoreset && d) {
-          blackjack_reset_one<FULL>(key, env, obs[j], hidden[j]);
+          if (FULL) blackjack_deal(deal_word[j], obs[j], hidden[j]);
+          else blackjack_reset_reference(key, env, obs[j], hidden[j]);
           steps[j] = 0;
         }
       }
@@ -200,7 +225,11 @@ __global__ void __launch_bounds__(kBlock) blackjack_reset_kernel(StepArgs a) {
   for (uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q < nquads; q += (uint64_t)gridDim.x * kBlock) {
     int32_t obs[4], hidden[4], zero[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int j = 0; j < 4; j++) blackjack_reset_one<FULL>(key, a.env_index_base + q * 4 + j, obs[j], hidden[j]);
+    for (int j = 0; j < 4; j++) {
+      const uint64_t env = a.env_index_base + q * 4 + j;
+      if (FULL) blackjack_deal(tabular_word(a.seed_lo, a.seed_hi, a.tick, env, kStreamDeal), obs[j], hidden[j]);
+      else blackjack_reset_reference(key, env, obs[j], hidden[j]);
+    }
     store4i(a.state_int, q, obs);
     store4i(a.state_int + a.stride, q, hidden);
     store4i(a.state_int + 2 * a.stride, q, zero);

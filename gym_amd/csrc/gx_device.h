@@ -43,7 +43,8 @@ constexpr int kStatFields = 6;
 // `tick` counts the Reset()/Step() calls made on the batch before the one that
 // consumes the draw, so no per-env RNG state is stored or moved.
 // Streams: 0 = Reset draws, 1 = draws made inside Step, 2 = random policy,
-// 3 = the per-tick word of the table-driven envs.
+// 3 = the per-tick word of the table-driven envs, 4 / 5 = the deal and dealer
+// words of Blackjack with upstream's rules (shared like stream 3).
 // The policy stream takes one draw per env per tick, so four consecutive ticks
 // share a block: tick t reads word t % 4 of the block whose counter holds
 // t / 4, and a fused K-step rollout runs the generator once every four steps.
@@ -110,14 +111,22 @@ __device__ __forceinline__ uint32_t policy_word(const Draws& d, uint64_t tick) {
   const uint32_t i = (uint32_t)tick & 3u;
   return i == 0 ? d.w[0] : (i == 1 ? d.w[1] : (i == 2 ? d.w[2] : d.w[3]));
 }
-// Table-driven envs: the block of the four envs 4g .. 4g+3 at a tick (stream 3).
-__device__ __forceinline__ Draws tabular_block(uint32_t seed_lo, uint32_t seed_hi, uint64_t tick, uint64_t env_group) {
-  return philox_block(make_key(seed_lo, seed_hi, tick), env_group, 3, 0);
+// Streams whose block is shared by the four envs 4g .. 4g+3 at a tick (3: the per-tick word of the table-driven
+// envs; 4 and 5: Blackjack's deal and dealer words), and env e's word of it.
+__device__ __forceinline__ Draws tabular_block(uint32_t seed_lo, uint32_t seed_hi, uint64_t tick, uint64_t env_group, uint32_t stream = 3) {
+  return philox_block(make_key(seed_lo, seed_hi, tick), env_group, stream, 0);
 }
-__device__ __forceinline__ uint32_t tabular_word(uint32_t seed_lo, uint32_t seed_hi, uint64_t tick, uint64_t env) {
-  const Draws d = tabular_block(seed_lo, seed_hi, tick, env >> 2);
+__device__ __forceinline__ uint32_t tabular_word(uint32_t seed_lo, uint32_t seed_hi, uint64_t tick, uint64_t env, uint32_t stream = 3) {
+  const Draws d = tabular_block(seed_lo, seed_hi, tick, env >> 2, stream);
   const uint32_t i = (uint32_t)env & 3u;
   return i == 0 ? d.w[0] : (i == 1 ? d.w[1] : (i == 2 ? d.w[2] : d.w[3]));
+}
+// The next base-n digit of u = w * 2^-32: returns floor(n u) and leaves the fraction of n u in w.  Successive
+// calls give independent draws below n out of one word, the k-th uniform to n^k * 2^-32.
+__device__ __forceinline__ int32_t word_next_digit(uint32_t& w, uint32_t n) {
+  const int32_t d = (int32_t)__umulhi(w, n);
+  w *= n;
+  return d;
 }
 // the outcome in [0, n_out) a table-driven env draws inside Step: the base-n_out digit that
 // follows the action digit of its word of the tick (see the stream list above)

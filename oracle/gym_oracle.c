@@ -46,7 +46,8 @@
  *     k = (w * n) >> 32  in [0,n)        (Next(n) stand-in)
  * with `tick` = number of Reset()/Step() calls made on the batch before the
  * one that consumes the draw.  Streams: 0 = Reset draws, 1 = draws an env
- * makes inside Step, 2 = action-space samples of the random policy.
+ * makes inside Step, 2 = action-space samples of the random policy, 3 = the
+ * per-tick word of the table-driven envs, 4 / 5 = Blackjack's deal and dealer words.
  * ====================================================================== */
 void gxo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
   uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
@@ -74,9 +75,10 @@ uint32_t gxo_rng_u32(uint64_t seed, uint64_t env_index, uint64_t tick, uint32_t 
     draw = (uint32_t)(tick & 3u);
     tick >>= 2;
   }
-  if (stream == 3) {
-    /* the per-tick word of the table-driven envs (FrozenLake, Taxi, CliffWalking, DummyEnv): four
-     * consecutive envs share a block (counter env / 4), env e reading word e % 4 */
+  if (stream >= 3) {
+    /* the per-tick word of the table-driven envs (FrozenLake, Taxi, CliffWalking, DummyEnv; stream 3) and the
+     * deal and dealer words of Blackjack under upstream's rules (streams 4, 5): four consecutive envs share a
+     * block (counter env / 4), env e reading word e % 4 */
     draw = (uint32_t)(env_index & 3u);
     env_index >>= 2;
   }
@@ -1002,6 +1004,13 @@ typedef struct {
 static inline int bj_card(int rank_index) { return rank_index + 1 < 10 ? rank_index + 1 : 10; }
 
 /* Envs.Blackjack.cs:21-30 */
+/* floor(13 u) for u = *w / 2^32, leaving the fraction of 13 u in *w: successive base-13 digits of one word */
+static int bj_next_digit13(uint32_t* w) {
+  uint64_t p = (uint64_t)*w * 13u;
+  *w = (uint32_t)p;
+  return (int)(p >> 32);
+}
+
 static void blackjack_reset(env_obj* e, const rng_ctx* r) {
   blackjack_t* c = (blackjack_t*)e;
   if (!c->full) {
@@ -1011,11 +1020,13 @@ static void blackjack_reset(env_obj* e, const rng_ctx* r) {
     c->hidden_sum = 0;
     c->hidden_ace = 0;
   } else {
-    /* EXTENSION (upstream Blackjack-v1): the dealer's two cards, then the player's two */
-    int d0 = bj_card(gxo_rng_below(r->seed, r->env_index, r->tick, 0, 0, 13));
-    int d1 = bj_card(gxo_rng_below(r->seed, r->env_index, r->tick, 0, 1, 13));
-    int p0 = bj_card(gxo_rng_below(r->seed, r->env_index, r->tick, 0, 2, 13));
-    int p1 = bj_card(gxo_rng_below(r->seed, r->env_index, r->tick, 0, 3, 13));
+    /* EXTENSION (upstream Blackjack-v1): the dealer's two cards, then the player's two: the first four base-13
+     * digits of the env's deal word of the tick (stream 4) */
+    uint32_t w = gxo_rng_u32(r->seed, r->env_index, r->tick, 4, 0);
+    int d0 = bj_card(bj_next_digit13(&w));
+    int d1 = bj_card(bj_next_digit13(&w));
+    int p0 = bj_card(bj_next_digit13(&w));
+    int p1 = bj_card(bj_next_digit13(&w));
     c->dealer_card = d0;
     c->hidden_sum = d1;
     c->hidden_ace = d1 == 1;
@@ -1048,14 +1059,17 @@ static int blackjack_step(env_obj* e, const void* action, const rng_ctx* r, doub
     *done = c->player_sum > 21;
     *reward = *done ? -1.0 : 0.0;
   } else {
-    /* the dealer draws to 17 or more (stream 1, draws 0, 1, ...), then the scores are compared */
+    /* the dealer draws to 17 or more, then the scores are compared: draws 0..3 are the first four base-13 digits
+     * of the env's dealer word of the tick (stream 5), later ones draws 0, 1, ... of the env's stream 1 */
     int raw = c->dealer_card + c->hidden_sum;
     int ace = c->dealer_card == 1 || c->hidden_ace;
+    uint32_t dw = gxo_rng_u32(r->seed, r->env_index, r->tick, 5, 0);
     uint32_t k = 0;
     for (;;) {
       int sum = raw + ((ace && raw + 10 <= 21) ? 10 : 0);
       if (sum >= 17) break;
-      int card = bj_card(gxo_rng_below(r->seed, r->env_index, r->tick, 1, k++, 13));
+      int card = k < 4 ? bj_card(bj_next_digit13(&dw)) : bj_card(gxo_rng_below(r->seed, r->env_index, r->tick, 1, k - 4, 13));
+      k++;
       raw += card;
       ace = ace || card == 1;
       c->hidden_sum += card;

@@ -45,15 +45,16 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 def rng_u32(seed, env, tick, stream, draw):
     """word (draw & 3) of the Philox block (draw >> 2) of this (env, tick, stream); the policy
     stream (2) has one draw per tick, word tick % 4 of the block of tick // 4; the per-tick word of
-    the table-driven envs (stream 3) is word env % 4 of the block of env // 4"""
+    the table-driven envs (stream 3) and Blackjack's deal and dealer words (4, 5) are word env % 4 of the
+    block of env // 4"""
     if stream == 2:
         draw, tick = tick & 3, tick >> 2
     env = np.asarray(env, np.uint64)
-    if stream == 3:
+    if stream >= 3:
         sel = (env & np.uint64(3)).astype(np.int64)
         env = env >> np.uint64(2)
         tick = int(tick)
-        c3 = np.uint64((3 << 24) | (((tick >> 32) & 0xFF) << 16))
+        c3 = np.uint64((stream << 24) | (((tick >> 32) & 0xFF) << 16))
         o = philox4x32_10(env & M32, env >> np.uint64(32), np.full_like(env, tick & 0xFFFFFFFF),
                           np.full_like(env, c3), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
         return np.choose(sel, o)
@@ -446,21 +447,35 @@ def _hand_value(hand):
     return (raw + 10 if usable else raw), int(usable)
 
 
+def _digits13(w, count):
+    """the first `count` base-13 digits of w / 2^32, per element"""
+    w = np.asarray(w, np.uint64)
+    out = []
+    for _ in range(count):
+        p = w * np.uint64(13)
+        out.append((p >> np.uint64(32)).astype(np.int64))
+        w = p & M32
+    return out
+
+
 def blackjack_full_deal(seed, env, tick):
-    """Extension (upstream Blackjack-v1 reset): dealer's two cards, then the player's two, from
-    stream 0.  Returns per-env [dealer hand, player hand] as Python lists of cards."""
-    cards = [DECK[rng_below(seed, env, tick, 0, d, 13)] for d in range(4)]
-    n = len(np.atleast_1d(env))
-    return [[[int(cards[0][i]), int(cards[1][i])], [int(cards[2][i]), int(cards[3][i])]] for i in range(n)]
+    """Extension (upstream Blackjack-v1 reset): dealer's two cards, then the player's two: the first four
+    base-13 digits of the env's deal word (stream 4).  Returns per-env [dealer hand, player hand] as
+    Python lists of cards."""
+    env = np.atleast_1d(np.asarray(env, np.uint64))
+    cards = [DECK[d] for d in _digits13(rng_u32(seed, env, tick, 4, 0), 4)]
+    return [[[int(cards[0][i]), int(cards[1][i])], [int(cards[2][i]), int(cards[3][i])]] for i in range(len(env))]
 
 
 def blackjack_full_step(hands, action, seed, env, tick):
     """Extension: upstream step (natural = False, sab = False) on the hands of blackjack_full_deal,
     updated in place; any non-zero action hits.  The hit card is the base-13 digit after the action
-    digit of the env's word of the tick (stream 3); the dealer's draws are stream 1, draws 0, 1, ..."""
+    digit of the env's word of the tick (stream 3); the dealer's first four draws are the base-13 digits
+    of the env's dealer word (stream 5), later ones stream 1, draws 0, 1, ..."""
     env = np.atleast_1d(np.asarray(env, np.uint64))
     w = rng_u32(seed, env, tick, 3, 0)
     hit_rank = ((w * np.uint64(26)) >> np.uint64(32)) % np.uint64(13)
+    dealer_ranks = _digits13(rng_u32(seed, env, tick, 5, 0), 4)
     reward = np.zeros(len(env))
     done = np.zeros(len(env), bool)
     for i, (dealer, player) in enumerate(hands):
@@ -471,7 +486,8 @@ def blackjack_full_step(hands, action, seed, env, tick):
         else:
             k = 0
             while _hand_value(dealer)[0] < 17:
-                dealer.append(int(DECK[int(rng_below(seed, env[i:i + 1], tick, 1, k, 13)[0])]))
+                rank = dealer_ranks[k][i] if k < 4 else rng_below(seed, env[i:i + 1], tick, 1, k - 4, 13)[0]
+                dealer.append(int(DECK[int(rank)]))
                 k += 1
             p, d = _hand_value(player)[0], _hand_value(dealer)[0]
             p, d = (0 if p > 21 else p), (0 if d > 21 else d)
