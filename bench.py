@@ -26,6 +26,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# RCCL shares buffers between ranks through dmabuf handles; the legacy IPC mode fails on hosts whose driver
+# only supports dmabuf (hipIpcGetMemHandle: invalid argument).  Inherited by the ranks spawn_ranks() starts.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
 def _gpus_from_argv(argv):
