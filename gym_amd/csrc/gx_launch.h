@@ -20,6 +20,13 @@ hipError_t launch_classic_sample(int env_id, const StepArgs& a, void* out, dim3 
 // the derived rows from the rows of the state image, after the image was written from outside (kEnvAcrobotAngles only)
 hipError_t launch_classic_derive(int env_id, const StepArgs& a, dim3 grid, hipStream_t stream);
 
+// Acrobot's part of the above (gx_acrobot.hip); env_id GX_ENV_ACROBOT or kEnvAcrobotAngles
+hipError_t launch_acrobot_step(int env_id, const StepArgs& a, int mode, int policy, bool fused, bool bounded, dim3 grid,
+                               hipStream_t stream);
+hipError_t launch_acrobot_reset(int env_id, const StepArgs& a, dim3 grid, hipStream_t stream);
+hipError_t launch_acrobot_sample(const StepArgs& a, void* out, dim3 grid, hipStream_t stream);
+hipError_t launch_acrobot_derive(const StepArgs& a, dim3 grid, hipStream_t stream);
+
 // the same five envs in binary64, GX_MODE_FP64 (gx_classic64.hip)
 hipError_t launch_classic64_step(int env_id, const StepArgs& a, int policy, bool fused, bool bounded, dim3 grid,
                                  hipStream_t stream);

@@ -11,7 +11,7 @@ SAN="-Xarch_host -fsanitize=address -Xarch_host -fsanitize=undefined -Xarch_host
 if [ "$1" = "build" ]; then
   mkdir -p $OUT
   objs=""
-  for f in gx_api.cpp gx_classic.hip gx_classic64.hip gx_acrobot64.hip gx_tabular.hip gx_blackjack.hip gx_pong.hip gx_breakout.hip gx_invaders.hip gx_stats.hip gx_hostpath.hip; do
+  for f in gx_api.cpp gx_classic.hip gx_acrobot.hip gx_classic64.hip gx_acrobot64.hip gx_tabular.hip gx_blackjack.hip gx_pong.hip gx_breakout.hip gx_invaders.hip gx_stats.hip gx_hostpath.hip; do
     x=""; [ "${f##*.}" = "cpp" ] && x="-x hip"
     $HIPCC --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt $SAN $x -c $R/gym_amd/csrc/$f -o $OUT/${f%.*}.o &
     objs="$objs $OUT/${f%.*}.o"
