@@ -5,7 +5,10 @@ One "step" = one VectorEnv.Step over the whole batch: CartPole-v1, 16 Mi
 envs per GPU, single-step kernel with auto-reset and RecordEpisodeStatistics
 fused, actions read from a device-resident array (zero-copy path), EXACT
 numeric mode.  State, actions and outputs are resident in HBM before the
-timed region starts.
+timed region starts, and the batch has been stepped out of its post-Reset()
+transient (--settle untimed steps: every env starts its first episode at the
+same tick, so the share of envs finishing per step -- which the fused
+auto-reset's cost follows -- takes tens of steps to reach its stationary rate).
 
   python bench.py --gpus 1 --steps 200 --warmup 20
   python bench.py --gpus N ...            (starts its own N ranks, one per GPU)
@@ -219,6 +222,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--settle", type=int, default=100,
+                    help="untimed steps after Reset() and before the warm-up, so that the batch is in the stationary regime "
+                         "of its policy (single-step workloads only)")
     ap.add_argument("--env", default="cartpole", choices=sorted(ENV_IDS))
     ap.add_argument("--num-envs", type=int, default=0, help="envs per GPU (default 16 Mi; Pong, Breakout 65536)")
     ap.add_argument("--policy", default="device", choices=["device", "random"])
@@ -331,6 +337,14 @@ def main():
         step_fn = lambda: batch.step_random(stream_ptr)  # noqa: E731
     torch.cuda.synchronize()
 
+    # Part of the set-up, like the resident inputs: the batch is stepped out of the state Reset() left it in.  All
+    # envs start their first episode together, so for the first tens of steps the share of envs that finish (and
+    # with it the cost of the fused auto-reset) swings before it settles at the policy's stationary rate
+    # (tools/step_time_series.py).  The W warm-up and K timed steps that follow see that stationary batch.
+    for _ in range(args.settle if k_roll == 1 else 0):
+        step_fn()
+    torch.cuda.synchronize()
+
     wall, kernel_ms = time_steps(batch, step_fn, args.steps, args.warmup, dist)
     total_steps = n * world * args.steps * k_roll
     value = total_steps / wall
@@ -365,6 +379,7 @@ def main():
                         "%s, %s mode" % (name, n, kind, "device-resident random actions, a ring of %d pre-sampled rows cycled per step (zero-copy path)" % ACTION_RING
                                          if args.policy == "device" else "actions sampled in-kernel", args.mode),
             "envs_per_gpu": n, "sharding": "independent env shards, no data-path collective",
+            "settle_steps_after_reset": args.settle if k_roll == 1 else 0,
         },
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
@@ -437,10 +452,16 @@ def extra_measurements(ctx, n, stream_ptr, dist, rank, world):
     base = rank * n
     b = DeviceBatch(ctx, L.ENV_ACROBOT, n, seed=1, flags=flags, env_index_base=base)
     b.reset()
-    steps = 20
-    wall, ms = time_steps(b, lambda: b.step_random(stream_ptr), steps, 3, dist)
+    # The cost of a fused step depends on how many envs finish in it (every wave with a finished env runs a reset
+    # round).  Reset() fills all six slots with small uniforms (Envs.Acrobot.cs:24-25), i.e. both angles are
+    # uniform on the circle, so the first steps after it end a large share of the episodes at once; the rate
+    # settles at 0.2-0.4 % of the envs per step after a few hundred steps (tools/step_time_series.py: 0.29 ms
+    # per step over the first 50 steps, 0.23-0.24 ms from step 150 on).  Timed in that stationary regime.
+    steps, settle = 100, 300
+    wall, ms = time_steps(b, lambda: b.step_random(stream_ptr), steps, settle, dist)
     res["acrobot_euler_exact_single_step"] = {"env_steps_per_s": n * world * steps / wall, "n_gpus": world, "kernel_ms": ms,
-                                             "hbm_GBps_per_gpu": (B_ALG["acrobot"] - 4) * n / (ms * 1e-3) / 1e9}
+                                             "hbm_GBps_per_gpu": (B_ALG["acrobot"] - 4) * n / (ms * 1e-3) / 1e9,
+                                             "untimed_steps_after_reset": settle, "timed_steps": steps}
     b.close()
     k = 64
     b = DeviceBatch(ctx, L.ENV_ACROBOT, n, seed=1, flags=flags | L.ACROBOT_RK4, env_index_base=base)
