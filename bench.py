@@ -92,7 +92,7 @@ from gym_amd.distributed import allreduce_stats, shard  # noqa: E402
 from gym_amd.engine import Context, DeviceBatch  # noqa: E402
 
 COLLECTIVE_DEVICE = "cuda"   # tensors handed to torch.distributed live here (cpu for the gloo rehearsal)
-ACTION_RING = 8              # pre-sampled action rows the device-actions policy cycles through
+ACTION_RING = int(os.environ.get("GYMX_BENCH_ACTION_RING", "8"))  # rows of pre-sampled actions cycled step by step
 HBM_PEAK_GBPS = 8000.0       # MI355X HBM3E peak
 FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X vector FP64 peak
 
@@ -450,6 +450,16 @@ def extra_measurements(ctx, n, stream_ptr, dist, rank, world):
         res["hbm_copy_ceiling_GBps_measured"] = d2d_copy_rate()
     flags = L.AUTORESET | L.RECORD_STATS
     base = rank * n
+    # the headline workload with the actions sampled in the kernel (Spaces.Discrete.Sample per env and step on the
+    # device) instead of read from a device row: 45 B per env-step
+    b = DeviceBatch(ctx, L.ENV_CARTPOLE, n, seed=1, flags=flags, env_index_base=base)
+    b.reset()
+    steps, settle = 100, 150
+    wall, ms = time_steps(b, lambda: b.step_random(stream_ptr), steps, settle, dist)
+    res["cartpole_actions_sampled_in_kernel"] = {"env_steps_per_s": n * world * steps / wall, "n_gpus": world, "kernel_ms": ms,
+                                                 "hbm_GBps_per_gpu": (B_ALG["cartpole"] - 4) * n / (ms * 1e-3) / 1e9,
+                                                 "untimed_steps_after_reset": settle, "timed_steps": steps}
+    b.close()
     b = DeviceBatch(ctx, L.ENV_ACROBOT, n, seed=1, flags=flags, env_index_base=base)
     b.reset()
     # The cost of a fused step depends on how many envs finish in it (every wave with a finished env runs a reset
