@@ -266,11 +266,14 @@ hipError_t launch_breakout_step(const StepArgs& a, int policy, dim3 grid, hipStr
 hipError_t launch_breakout_reset(const StepArgs& a, dim3 grid, hipStream_t stream) { return launch_frame_reset<BreakoutGame>(a, grid, stream); }
 hipError_t launch_breakout_raster(const StepArgs& a, uint8_t* frames, hipStream_t stream) {
   if (a.num_envs == 0) return hipSuccess;
-  // tuning aid: GYMX_FRAME_RASTER=<threads>,<workgroups per frame>, threads 64, 128 or 256
-  // One 256-thread workgroup per frame.  Unlike Pong's, this raster gains nothing from shorter workgroups
-  // (65 536 envs, step + raster: 1.23 ms as is; 64 or 128 threads x 9..50 workgroups per frame 1.5-1.95 ms,
-  // and still 1.24-1.32 ms with the eleven state loads of a workgroup replaced by one packed record).
-  static int threads = 256, split = 1;
+  // Nine consecutive one-wave workgroups per frame, eleven 1 KiB steps each.  What this part sustains for such a
+  // write-only stream depends on the shape of the launch more than on anything else, and not smoothly: at 65 536
+  // envs (step + raster, ms) one 256-thread workgroup per frame 1.23; 64 threads x 9 workgroups 1.087, x 10 1.10,
+  // x 8 1.22, x 6 1.23, x 12 1.13, x 22..66 1.8-2.7; 128 x 5 1.09, x 6 1.18, x 3 1.22, x 7 1.31; 256 x 2 1.11,
+  // x 3 1.11, x 4 1.44 (tools/raster_shape_scan.sh scans them all).  Every workgroup pays the state loads again,
+  // which is what the many-part shapes lose to.
+  // Tuning aid: GYMX_FRAME_RASTER=<threads>,<workgroups per frame>, threads 64, 128 or 256.
+  static int threads = 64, split = 9;
   static const bool parsed = [] {
     const char* s = std::getenv("GYMX_FRAME_RASTER");
     int t = 0, sp = 0;

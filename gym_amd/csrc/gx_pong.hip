@@ -198,21 +198,24 @@ hipError_t launch_pong_step(const StepArgs& a, int policy, dim3 grid, hipStream_
 hipError_t launch_pong_reset(const StepArgs& a, dim3 grid, hipStream_t stream) { return launch_frame_reset<PongGame>(a, grid, stream); }
 hipError_t launch_pong_raster(const StepArgs& a, uint8_t* frames, hipStream_t stream) {
   if (a.num_envs == 0) return hipSuccess;
-  // 17 consecutive two-wave workgroups per frame, three 2 KiB steps each.  Measured at 65 536 envs (step +
-  // raster, ms): one 256-thread workgroup walking a whole frame 1.21; 64 threads x 10..25 workgroups per
-  // frame 1.20; 64 x 34 and 128 x 17 (three steps per wave) 1.09; 64 x 50 and 128 x 25 (two steps) 1.35.
-  // Tuning aid: GYMX_PONG_RASTER=<threads>,<workgroups per frame>, threads 64, 128 or 256.
-  static int threads = 128, split = 17;
+  // Ten consecutive four-wave workgroups per frame, three 4 KiB steps each (the tenth workgroup of a frame finds
+  // nothing left and retires).  Measured at 65 536 envs (step + raster, ms): one 256-thread workgroup walking a
+  // whole frame 1.21; 64 threads x 10..25 workgroups per frame 1.20; three steps per wave: 64 x 34 and 128 x 17
+  // 1.09, 256 x 9 1.06, 256 x 10 1.04, 512 x 5 1.07; two steps (64 x 50, 128 x 25) 1.35; four (256 x 8) 1.37.
+  // Tuning aid: GYMX_PONG_RASTER=<threads>,<workgroups per frame>, threads 64, 128, 256, 512 or 1024.
+  static int threads = 256, split = 10;
   static const bool parsed = [] {
     const char* s = std::getenv("GYMX_PONG_RASTER");
     int t = 0, sp = 0;
-    if (s && std::sscanf(s, "%d,%d", &t, &sp) == 2 && (t == 64 || t == 128 || t == 256) && sp >= 1 && sp <= 128) { threads = t; split = sp; }
+    if (s && std::sscanf(s, "%d,%d", &t, &sp) == 2 && (t == 64 || t == 128 || t == 256 || t == 512 || t == 1024) && sp >= 1 && sp <= 128) { threads = t; split = sp; }
     return true;
   }();
   (void)parsed;
   const dim3 grid((unsigned)(a.num_envs * (uint64_t)split));
   if (threads == 64) hipLaunchKernelGGL(pong_raster16_kernel<64>, grid, dim3(64), 0, stream, a, frames, split);
   else if (threads == 128) hipLaunchKernelGGL(pong_raster16_kernel<128>, grid, dim3(128), 0, stream, a, frames, split);
+  else if (threads == 512) hipLaunchKernelGGL(pong_raster16_kernel<512>, grid, dim3(512), 0, stream, a, frames, split);
+  else if (threads == 1024) hipLaunchKernelGGL(pong_raster16_kernel<1024>, grid, dim3(1024), 0, stream, a, frames, split);
   else hipLaunchKernelGGL(pong_raster16_kernel<256>, grid, dim3(256), 0, stream, a, frames, split);
   return hipGetLastError();
 }
