@@ -81,6 +81,7 @@ struct gx_vec {
   int num_slots = 0;
   float* d_obs = nullptr;
   uint8_t* d_frames = nullptr;
+  uint32_t* d_render = nullptr;  // frame envs: one packed record per env between the step and the raster
   uint32_t* d_table = nullptr;
   uint32_t* d_error = nullptr;
   void* d_actions = nullptr;  // staging for the host path
@@ -443,6 +444,14 @@ hipError_t frame_reset(const gx_vec* v, const StepArgs& a, hipStream_t stream) {
     default: return launch_invaders_reset(a, v->grid, stream);
   }
 }
+// the render records again, after the states were written from outside
+hipError_t frame_pack(const gx_vec* v, const StepArgs& a, hipStream_t stream) {
+  switch (v->desc.env_id) {
+    case GX_ENV_PONG: return launch_pong_pack(a, v->grid, stream);
+    case GX_ENV_BREAKOUT: return launch_breakout_pack(a, v->grid, stream);
+    default: return launch_invaders_pack(a, v->grid, stream);
+  }
+}
 hipError_t frame_raster(const gx_vec* v, const StepArgs& a, hipStream_t stream) {
   switch (v->desc.env_id) {
     case GX_ENV_PONG: return launch_pong_raster(a, v->d_frames, stream);
@@ -464,6 +473,7 @@ StepArgs make_args(const gx_vec* v, const void* d_actions, int k_steps, uint64_t
   a.stat_slots = v->d_slots;
   a.obs = v->d_obs;
   a.table = v->d_table;
+  a.render = v->d_render;
   a.error_flag = v->d_error;
   a.num_envs = v->n;
   a.stride = v->stride;
@@ -563,7 +573,7 @@ extern "C" int gx_vec_destroy(gx_vec* v) {
     (void)hipStreamSynchronize(v->ctx->copy);
   }
   void* dev[] = {v->d_real, v->d_int, v->d_reward, v->d_done, v->d_trunc, v->d_ep_return, v->d_ep_length,
-                 v->d_slots, v->d_obs, v->d_frames, v->d_table, v->d_error, v->d_actions};
+                 v->d_slots, v->d_obs, v->d_frames, v->d_render, v->d_table, v->d_error, v->d_actions};
   for (void* p : dev)
     if (p) (void)hipFree(p);
   if (v->h_error) (void)hipHostFree(v->h_error);
@@ -674,6 +684,9 @@ extern "C" int gx_vec_create(gx_ctx* ctx, const gx_desc* desc, gx_vec** out) {
     }
   }
   if (v->is_frame) VEC_TRY(hipMalloc((void**)&v->d_frames, v->n * (size_t)in.obs_dim));
+  if (env == GX_ENV_SPACEINVADERS) VEC_TRY(hipMalloc((void**)&v->d_render, v->n * kInvadersRecordBytes));
+  if (env == GX_ENV_BREAKOUT) VEC_TRY(hipMalloc((void**)&v->d_render, v->n * kBreakoutRecordBytes));
+  if (env == GX_ENV_PONG) VEC_TRY(hipMalloc((void**)&v->d_render, v->n * kPongRecordBytes));
 
   // launch geometry: workgroups grid-stride over lanes of `envs_per_lane` envs, two trips
   // each.  Measured on CartPole, MountainCar, Pendulum and FrozenLake at 4 Mi to 64 Mi envs:
@@ -835,7 +848,10 @@ extern "C" int gx_vec_set_state(gx_vec* v, const void* host, size_t bytes) {
   HIP_TRY(hipStreamSynchronize(c->copy));
   v->state_dirty = true;
   StepArgs a = make_args(v, nullptr, 1, 0);
-  if (v->is_frame) HIP_TRY(frame_raster(v, a, c->compute));
+  if (v->is_frame) {
+    HIP_TRY(frame_pack(v, a, c->compute));
+    HIP_TRY(frame_raster(v, a, c->compute));
+  }
   if (v->is_acrobot64) HIP_TRY(launch_acrobot64_reset(a, 1, v->grid, c->compute));
   if (v->acrobot_angles) HIP_TRY(launch_classic_derive(v->classic_id, a, v->grid, c->compute));
   HIP_TRY(hipStreamSynchronize(c->compute));

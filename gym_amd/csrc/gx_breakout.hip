@@ -160,6 +160,18 @@ struct BreakoutGame {
     bk::step(s, action, key, env, reward, done);
   }
   static __device__ __forceinline__ int32_t steps(const State& s) { return s.steps; }
+  // 0 (int)paddleX, 1-2 the ball's corner, 3 lives, 4 score, 5-8 the 108 brick bits
+  static constexpr int kRecordDwords = 16;
+  static __device__ __forceinline__ void pack(const State& s, uint32_t* record) {
+    // (int) casts truncate toward zero, Envs.Breakout.cs:263-274
+    const int px = (int)s.paddleX;
+    const int bx = (int)(s.stuck ? s.paddleX + bk::kPaddleW / 2.0 - bk::kBallSize / 2.0 : s.ballX);
+    const int by = s.stuck ? kScreenH - 30 : (int)s.ballY;
+    int4* out = reinterpret_cast<int4*>(record);
+    out[0] = make_int4(px, bx, by, s.lives);
+    out[1] = make_int4(s.score, (int)s.bricks[0], (int)s.bricks[1], (int)s.bricks[2]);
+    out[2] = make_int4((int)s.bricks[3], 0, 0, 0);
+  }
 };
 
 // The frame in 16-byte chunks (gx_frame.h), `split` consecutive workgroups of THREADS lanes per env.
@@ -170,34 +182,17 @@ struct BreakoutGame {
 // brick colour it hides (the reference paints bricks first and everything white after them,
 // Envs.Breakout.cs:229-285).
 template <int THREADS>
-__global__ void __launch_bounds__(THREADS) breakout_raster_kernel(StepArgs a, uint8_t* __restrict__ frames, int split) {
+__global__ void __launch_bounds__(THREADS) breakout_raster_kernel(StepArgs a, uint8_t* __restrict__ frames, RasterLaunch g) {
   __shared__ uint32_t digit_rows[5][6];  // rows 10..14 as 160-bit masks, plus a zero word for the 64-bit window
-  // the parts of a frame are consecutive workgroups: workgroups in flight together write neighbouring memory
-  const uint64_t env = blockIdx.x / (uint32_t)split;
-  const int part = (int)(blockIdx.x % (uint32_t)split);
-  constexpr int kChunksPerRow = kScreenW * 3 / 16, kChunks = kFrameBytes / 16;
-  // A frame starts 16-byte but not cache-line aligned (100 800 = 787.5 x 128): the steps are laid on the frame
-  // buffer's own THREADS x 16-byte grid, the first and the last step of a frame partly masked, so that no
-  // cache line is written by two workgroups (consecutive workgroups run on different XCDs, each with its own L2).
-  const int head = (int)((env * (uint64_t)kChunks) & (THREADS - 1));
-  const int steps = (head + kChunks + THREADS - 1) / THREADS;
-  const int per_part = (steps + split - 1) / split;
-  const int c_first = part * per_part * THREADS - head, c_end = min(kChunks, (part + 1) * per_part * THREADS - head);
-  if (c_first >= c_end) return;
-  const double* r = static_cast<const double*>(a.state_real);
-  const int32_t* n = a.state_int;
-  // every load is issued before the first use: one round trip to memory per workgroup, not one per branch
-  const double ballX = r[env], ballY = r[a.stride + env], paddleX = r[4 * a.stride + env];
-  const int32_t stuck_word = n[2 * a.stride + env];
-  const int lives = n[a.stride + env], score = n[env];
+  constexpr int kChunksPerRow = kScreenW * 3 / 16;
+  uint64_t env;
+  int c_first, c_end;
+  if (!raster_part<THREADS>(g, env, c_first, c_end)) return;
+  const uint32_t* rec = a.render + env * BreakoutGame::kRecordDwords;
+  const int px = (int)rec[0], bx = (int)rec[1], by = (int)rec[2], lives = (int)rec[3], score = (int)rec[4];
   // the 108 brick bits as two 64-bit halves (no indexed array: it would be placed in LDS)
-  const uint64_t bricks_lo = (uint64_t)(uint32_t)n[3 * a.stride + env] | ((uint64_t)(uint32_t)n[4 * a.stride + env] << 32);
-  const uint64_t bricks_hi = (uint64_t)(uint32_t)n[5 * a.stride + env] | ((uint64_t)(uint32_t)n[6 * a.stride + env] << 32);
-  const bool stuck = stuck_word != 0;
-  // (int) casts truncate toward zero, Envs.Breakout.cs:263-274
-  const int px = (int)paddleX;
-  const int bx = (int)(stuck ? paddleX + bk::kPaddleW / 2.0 - bk::kBallSize / 2.0 : ballX);
-  const int by = stuck ? kScreenH - 30 : (int)ballY;
+  const uint64_t bricks_lo = (uint64_t)rec[5] | ((uint64_t)rec[6] << 32);
+  const uint64_t bricks_hi = (uint64_t)rec[7] | ((uint64_t)rec[8] << 32);
   // the score rows 10..14 are chunks 300..449: only a workgroup that covers some of them builds their masks
   if (c_first < 15 * kChunksPerRow && c_end > 10 * kChunksPerRow) {
     if (threadIdx.x < 30) digit_rows[threadIdx.x / 6][threadIdx.x % 6] = 0;
@@ -264,28 +259,20 @@ __global__ void __launch_bounds__(THREADS) breakout_raster_kernel(StepArgs a, ui
 
 hipError_t launch_breakout_step(const StepArgs& a, int policy, dim3 grid, hipStream_t stream) { return launch_frame_step<BreakoutGame>(a, policy, grid, stream); }
 hipError_t launch_breakout_reset(const StepArgs& a, dim3 grid, hipStream_t stream) { return launch_frame_reset<BreakoutGame>(a, grid, stream); }
+static_assert(BreakoutGame::kRecordDwords * 4 == kBreakoutRecordBytes, "the render records are allocated by this size");
+hipError_t launch_breakout_pack(const StepArgs& a, dim3 grid, hipStream_t stream) { return launch_frame_pack<BreakoutGame>(a, grid, stream); }
 hipError_t launch_breakout_raster(const StepArgs& a, uint8_t* frames, hipStream_t stream) {
   if (a.num_envs == 0) return hipSuccess;
-  // Nine consecutive one-wave workgroups per frame, eleven 1 KiB steps each.  What this part sustains for such a
-  // write-only stream depends on the shape of the launch more than on anything else, and not smoothly: at 65 536
-  // envs (step + raster, ms) one 256-thread workgroup per frame 1.23; 64 threads x 9 workgroups 1.087, x 10 1.10,
-  // x 8 1.22, x 6 1.23, x 12 1.13, x 22..66 1.8-2.7; 128 x 5 1.09, x 6 1.18, x 3 1.22, x 7 1.31; 256 x 2 1.11,
-  // x 3 1.11, x 4 1.44 (tools/raster_shape_scan.sh scans them all).  Every workgroup pays the state loads again,
-  // which is what the many-part shapes lose to.
-  // Tuning aid: GYMX_FRAME_RASTER=<threads>,<workgroups per frame>, threads 64, 128 or 256.
-  static int threads = 64, split = 9;
-  static const bool parsed = [] {
-    const char* s = std::getenv("GYMX_FRAME_RASTER");
-    int t = 0, sp = 0;
-    if (s && std::sscanf(s, "%d,%d", &t, &sp) == 2 && (t == 64 || t == 128 || t == 256) && sp >= 1 && sp <= 128) { threads = t; split = sp; }
-    return true;
-  }();
-  (void)parsed;
-  const dim3 grid((unsigned)(a.num_envs * (uint64_t)split));
-  if (threads == 64) hipLaunchKernelGGL(breakout_raster_kernel<64>, grid, dim3(64), 0, stream, a, frames, split);
-  else if (threads == 128) hipLaunchKernelGGL(breakout_raster_kernel<128>, grid, dim3(128), 0, stream, a, frames, split);
-  else hipLaunchKernelGGL(breakout_raster_kernel<256>, grid, dim3(256), 0, stream, a, frames, split);
-  return hipGetLastError();
+  // 30 two-wave workgroups per frame, two 2 KiB steps each (see the Pong raster).  Measured at 65 536 envs (step +
+  // raster, ms): 128 x 30 0.957, x 28 0.965, x 26 0.967, x 25 0.993; 256 x 13 0.964, x 14 0.982, x 12 1.02;
+  // 64 x 34 1.00; three steps per wave 1.04-1.05; one 256-thread workgroup per frame 1.15
+  // (tools/raster_shape_scan.sh, tools/raster_shape_ab.sh).
+  static const RasterShape shape = raster_shape_from_env("GYMX_FRAME_RASTER", RasterShape{128, 30}, 256);
+  return launch_raster_slices(a.num_envs, shape.threads, shape.split, [&](dim3 grid, const RasterLaunch& g) {
+    if (shape.threads == 64) hipLaunchKernelGGL(breakout_raster_kernel<64>, grid, dim3(64), 0, stream, a, frames, g);
+    else if (shape.threads == 128) hipLaunchKernelGGL(breakout_raster_kernel<128>, grid, dim3(128), 0, stream, a, frames, g);
+    else hipLaunchKernelGGL(breakout_raster_kernel<256>, grid, dim3(256), 0, stream, a, frames, g);
+  });
 }
 hipError_t launch_breakout_sample(const StepArgs& a, void* out, dim3 grid, hipStream_t stream) { return launch_frame_sample<BreakoutGame>(a, out, grid, stream); }
 

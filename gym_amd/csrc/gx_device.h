@@ -279,6 +279,7 @@ struct StepArgs {
   float* obs;              // derived observation rows, or nullptr
   const uint32_t* table;   // tabular envs: packed transition table
   uint32_t* error_flag;    // set non-zero by a kernel that meets an action the reference throws on
+  uint32_t* render;        // frame envs: [num_envs][G::kRecordDwords], what the raster reads of each env's state
   // per-step outputs of a K-step rollout (gx_vec_rollout_out, GX_OUT_ALL): row k holds step k's
   // values; nullptr = not wanted
   void* out_reward;        // [k_steps][stride] float or double

@@ -6,6 +6,8 @@
 // to back.
 #pragma once
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 
 #include <hip/hip_runtime.h>
 
@@ -112,6 +114,62 @@ __device__ __forceinline__ void score_row_mask(uint32_t* mask, int score, int ro
       if (((g >> dx) & 1u) && px >= 0 && px < kScreenW) atomicOr(&mask[px >> 5], 1u << (px & 31));
     }
   }
+}
+
+
+// Launch geometry of the three rasters.  A frame is written by `split` workgroups (its parts), each a run of
+// whole steps of THREADS x 16 bytes laid on the frame buffer's own THREADS x 16-byte grid (a frame starts 16-byte
+// but not cache-line aligned, 100 800 = 787.5 x 128: the first and the last step of a frame are partly masked, and
+// no cache line is written by two workgroups).
+//
+// The hardware deals the workgroups of a grid to the eight XCDs in turn, in the order x fastest, then y, then z:
+// with grid = (8, split, frames per XCD) blockIdx.x IS the XCD a workgroup runs on, and XCD x writes the x-th
+// eighth of the batch's frames in order -- one forward-moving stretch of the frame buffer per XCD (per L2)
+// rather than every eighth piece of one stretch shared with the other seven.  Measured, the write rate then varies
+// smoothly with the launch shape; with one linear grid in launch order it jumped by 30 % between neighbouring
+// shapes.  The three indices also spare every wave the divisions by `split` a linear index needs (about sixty
+// scalar instructions: short workgroups are bound by the scalar unit, which all waves of a CU share).
+struct RasterLaunch {
+  uint64_t env_first;    // this launch covers envs [env_first, env_first + env_count)
+  uint32_t env_count, envs_per_xcd;
+  int per_part[2];       // steps per part of a frame of kSteps / kSteps + 1 steps
+};
+template <int THREADS>
+__device__ __forceinline__ bool raster_part(const RasterLaunch& g, uint64_t& env, int& c_first, int& c_end) {
+  constexpr int kChunks = kFrameBytes / 16, kSteps = (kChunks + THREADS - 1) / THREADS;
+  const uint32_t local = blockIdx.x * g.envs_per_xcd + blockIdx.z;
+  if (local >= g.env_count) return false;
+  env = g.env_first + local;
+  const int head = (int)((env * (uint64_t)kChunks) & (THREADS - 1));
+  const int steps = (head + kChunks + THREADS - 1) / THREADS;  // kSteps or one more
+  const int per_part = steps == kSteps ? g.per_part[0] : g.per_part[1];
+  const int part = (int)blockIdx.y;
+  c_first = part * per_part * THREADS - head;
+  c_end = min(kChunks, (part + 1) * per_part * THREADS - head);
+  return c_first < c_end;
+}
+// launch(grid, geometry) once per slice of the batch a grid can hold (z <= 65 535: 524 280 frames)
+template <class F>
+hipError_t launch_raster_slices(uint64_t num_envs, int threads, int split, F&& launch) {
+  const int steps = (kFrameBytes / 16 + threads - 1) / threads;
+  constexpr uint64_t kSlice = 8ull * 65535ull;
+  for (uint64_t first = 0; first < num_envs; first += kSlice) {
+    const uint64_t count = num_envs - first < kSlice ? num_envs - first : kSlice;
+    RasterLaunch g{first, (uint32_t)count, (uint32_t)((count + 7) / 8), {(steps + split - 1) / split, (steps + split) / split}};
+    launch(dim3(8u, (unsigned)split, g.envs_per_xcd), g);
+  }
+  return hipGetLastError();
+}
+
+// GYMX_FRAME_RASTER (Pong: GYMX_PONG_RASTER) = <threads>,<workgroups per frame>: the tuning aid of the three
+// raster launchers
+struct RasterShape { int threads, split; };
+inline RasterShape raster_shape_from_env(const char* var, RasterShape dflt, int max_threads) {
+  const char* s = std::getenv(var);
+  int t = 0, sp = 0;
+  if (s && std::sscanf(s, "%d,%d", &t, &sp) == 2 && t >= 64 && t <= max_threads && (t & (t - 1)) == 0 && sp >= 1 && sp <= 128)
+    return RasterShape{t, sp};
+  return dflt;
 }
 
 }  // namespace gx

@@ -5,7 +5,11 @@
 //              static void load(const StepArgs&, uint64_t i, State&); static void store(...);
 //              static void reset(State&, const RngKey&, uint64_t env);
 //              static void step(State&, int action, const RngKey&, uint64_t env, float& reward, bool& done);
-//              static int32_t steps(const State&); };
+//              static int32_t steps(const State&);
+//              static constexpr int kRecordDwords; static void pack(const State&, uint32_t* record); };
+// pack() writes what the game's raster needs of a state as one short record: the raster's workgroups (several
+// per frame) then read one cache line each instead of one line per state row.  The step and reset kernels write
+// the records as they store the states; frame_pack_kernel rebuilds them after the states were written from outside.
 #pragma once
 
 #include "gx_device.h"
@@ -59,6 +63,7 @@ __global__ void __launch_bounds__(kBlock) frame_step_kernel(StepArgs a) {
       }
     }
     G::store(a, i, s);
+    if (a.render) G::pack(s, a.render + i * G::kRecordDwords);
     if (record) {
       static_cast<int32_t*>(a.ep_return)[i] = ep_ret;
       if (a.ep_length) a.ep_length[i] = ep_len;
@@ -79,6 +84,16 @@ __global__ void __launch_bounds__(kBlock) frame_reset_kernel(StepArgs a) {
     typename G::State s;
     G::reset(s, key, a.env_index_base + i);
     G::store(a, i, s);
+    G::pack(s, a.render + i * G::kRecordDwords);
+  }
+}
+
+template <class G>
+__global__ void __launch_bounds__(kBlock) frame_pack_kernel(StepArgs a) {
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < a.num_envs; i += (uint64_t)gridDim.x * kBlock) {
+    typename G::State s;
+    G::load(a, i, s);
+    G::pack(s, a.render + i * G::kRecordDwords);
   }
 }
 
@@ -100,6 +115,11 @@ hipError_t launch_frame_step(const StepArgs& a, int policy, dim3 grid, hipStream
 template <class G>
 hipError_t launch_frame_reset(const StepArgs& a, dim3 grid, hipStream_t stream) {
   hipLaunchKernelGGL(frame_reset_kernel<G>, grid, dim3(kBlock), 0, stream, a);
+  return hipGetLastError();
+}
+template <class G>
+hipError_t launch_frame_pack(const StepArgs& a, dim3 grid, hipStream_t stream) {
+  hipLaunchKernelGGL(frame_pack_kernel<G>, grid, dim3(kBlock), 0, stream, a);
   return hipGetLastError();
 }
 template <class G>

@@ -243,7 +243,49 @@ struct InvadersGame {
     si::step(s, action, key, env, reward, done);
   }
   static __device__ __forceinline__ int32_t steps(const State& s) { return s.steps; }
+  // 0 (int)playerX, 1 score, 2 life cannons shown, 3 player bullets | alien bullets << 8 (both clamped to the
+  // slots), 4-5 alien bits, 6-7 / 8-9 the formation's origin (doubles: column and row origins are casts of sums
+  // with it), 10-12 / 13-15 player bullet x / y, 16-17 / 18-19 alien bullet x / y, 20-27 the rows
+  // that are not blank; padded to a cache line
+  static constexpr int kRecordDwords = 32, kRowMaskAt = 20;
+  static __device__ __forceinline__ void pack(const State& s, uint32_t* record) {
+    const int npb = s.npb > si::kMaxPB ? si::kMaxPB : (s.npb < 0 ? 0 : s.npb);
+    const int nab = s.nab > si::kMaxAB ? si::kMaxAB : (s.nab < 0 ? 0 : s.nab);
+    int4* out = reinterpret_cast<int4*>(record);
+    // cannon 13 of the lives would start at x = -10
+    out[0] = make_int4((int)s.playerX, s.score, s.lives < 0 ? 0 : (s.lives > 13 ? 13 : s.lives), npb | (nab << 8));
+    out[1] = make_int4((int32_t)(uint32_t)s.aliens, (int32_t)(uint32_t)(s.aliens >> 32), __double2loint(s.formX), __double2hiint(s.formX));
+    out[2] = make_int4(__double2loint(s.formY), __double2hiint(s.formY), (int)s.pbx[0], (int)s.pbx[1]);
+    out[3] = make_int4((int)s.pbx[2], (int)s.pby[0], (int)s.pby[1], (int)s.pby[2]);
+    out[4] = make_int4((int)s.abx[0], (int)s.abx[1], (int)s.aby[0], (int)s.aby[1]);
+    // dwords 20-27: bit y set = something can touch frame row y (most rows are blank), the eighth dword zero
+    uint32_t m[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    auto add_rows = [&](int first, int count) {  // count <= 6
+#pragma unroll
+      for (int d = 0; d < 7; d++) {
+        int lo = first - 32 * d, hi = lo + count;
+        lo = lo < 0 ? 0 : lo;
+        hi = hi > 32 ? 32 : hi;
+        if (lo < hi) m[d] |= ((1u << (hi - lo)) - 1u) << lo;
+      }
+    };
+#pragma unroll
+    for (int q = 0; q < si::kRows; q++)
+      if (((s.aliens >> (q * si::kCols)) & ((1ull << si::kCols) - 1ull)) != 0ull) add_rows((int)(s.formY + q * 10), 6);
+    add_rows(kScreenH - 40, 6);  // the cannon
+#pragma unroll
+    for (int b = 0; b < si::kMaxPB; b++)
+      if (b < npb) add_rows((int)s.pby[b], 4);
+#pragma unroll
+    for (int b = 0; b < si::kMaxAB; b++)
+      if (b < nab) add_rows((int)s.aby[b], 4);
+    add_rows(10, 6);              // score and lives
+    add_rows(kScreenH - 20, 2);  // ground line
+    out[5] = make_int4((int)m[0], (int)m[1], (int)m[2], (int)m[3]);
+    out[6] = make_int4((int)m[4], (int)m[5], (int)m[6], 0);
+  }
 };
+static_assert(si::kMaxPB == 3 && si::kMaxAB == 2, "the record's bullet slots");
 
 // palette of the frame: index -> r | g << 8 | b << 16
 enum : uint32_t { kBlack = 0, kMagenta, kCyan, kYellow, kGreen, kRed, kWhite };
@@ -260,73 +302,46 @@ __device__ __forceinline__ uint32_t palette(uint32_t idx) {
 // painting into a frame does; a pixel off the screen is never visited, which is the reference's
 // DrawRectangle bounds check (:461-478).
 template <int THREADS>
-__global__ void __launch_bounds__(THREADS) invaders_raster_kernel(StepArgs a, uint8_t* __restrict__ frames, int split) {
+__global__ void __launch_bounds__(THREADS) invaders_raster_kernel(StepArgs a, uint8_t* __restrict__ frames, RasterLaunch g) {
   __shared__ uint32_t digit_rows[5][6];  // rows 10..14 of the frame as 160-bit masks (the score), plus a zero word for the 64-bit window
-  __shared__ int32_t alien_x[si::kCols], alien_y[si::kRows];
-  __shared__ uint8_t row_layers[kScreenH];  // which layers can touch a frame row (most rows: none)
-  // the parts of a frame are consecutive workgroups, their steps laid on the frame buffer's own THREADS x 16-byte
-  // grid (see the Breakout raster)
-  const uint64_t env = blockIdx.x / (uint32_t)split;
-  const int part = (int)(blockIdx.x % (uint32_t)split);
+  constexpr int kChunksPerRow = kScreenW * 3 / 16;
   const int tid = threadIdx.x;
-  constexpr int kChunksPerRow = kScreenW * 3 / 16, kChunks = kFrameBytes / 16;
-  const int head = (int)((env * (uint64_t)kChunks) & (THREADS - 1));
-  const int steps = (head + kChunks + THREADS - 1) / THREADS;
-  const int per_part = (steps + split - 1) / split;
-  const int c_first = part * per_part * THREADS - head, c_end = min(kChunks, (part + 1) * per_part * THREADS - head);
-  if (c_first >= c_end) return;
-  const double* r = static_cast<const double*>(a.state_real);
-  const int32_t* n = a.state_int;
-  // every load is issued before the first barrier: one round trip to memory per workgroup
-  const double formX = r[a.stride + env], formY = r[2 * a.stride + env];
-  const int32_t score = n[env];
-  const uint64_t aliens = (uint64_t)(uint32_t)n[6 * a.stride + env] | ((uint64_t)(uint32_t)n[7 * a.stride + env] << 32);
-  const int player_x = (int)r[env];
-  const int lives = n[a.stride + env];
-  const int shown = lives < 0 ? 0 : (lives > 13 ? 13 : lives);  // cannon 13 would start at x = -10
-  int npb = n[4 * a.stride + env], nab = n[5 * a.stride + env];
-  npb = npb > si::kMaxPB ? si::kMaxPB : npb;
-  nab = nab > si::kMaxAB ? si::kMaxAB : nab;
-  int pbx[si::kMaxPB], pby[si::kMaxPB], abx[si::kMaxAB], aby[si::kMaxAB];
-#pragma unroll
-  for (int b = 0; b < si::kMaxPB; b++) { pbx[b] = (int)r[(3 + 2 * b) * a.stride + env]; pby[b] = (int)r[(4 + 2 * b) * a.stride + env]; }
-#pragma unroll
-  for (int b = 0; b < si::kMaxAB; b++) { abx[b] = (int)r[(9 + 2 * b) * a.stride + env]; aby[b] = (int)r[(10 + 2 * b) * a.stride + env]; }
+  uint64_t env;
+  int c_first, c_end;
+  if (!raster_part<THREADS>(g, env, c_first, c_end)) return;
+  // the env's record: one cache line, read with scalar loads (the address is the same for every lane)
+  const uint32_t* rec = a.render + env * InvadersGame::kRecordDwords;
+  const int player_x = (int)rec[0];
+  const int32_t score = (int32_t)rec[1];
+  const int shown = (int)rec[2];
+  const int npb = (int)(rec[3] & 0xFFu), nab = (int)(rec[3] >> 8);
+  const uint64_t aliens = (uint64_t)rec[4] | ((uint64_t)rec[5] << 32);
+  const double formX = __hiloint2double((int)rec[7], (int)rec[6]), formY = __hiloint2double((int)rec[9], (int)rec[8]);
+  const int pbx[si::kMaxPB] = {(int)rec[10], (int)rec[11], (int)rec[12]}, pby[si::kMaxPB] = {(int)rec[13], (int)rec[14], (int)rec[15]};
+  const int abx[si::kMaxAB] = {(int)rec[16], (int)rec[17]}, aby[si::kMaxAB] = {(int)rec[18], (int)rec[19]};
   // column / row origins exactly as the source computes them, (int)(formation + 12 col) and
   // (int)(formation + 10 row): the cast truncates toward zero, so consecutive origins are 12 (10)
   // apart give or take one
-  if (tid < si::kCols) alien_x[tid] = (int)(formX + tid * 12);
-  if (tid < si::kRows) alien_y[tid] = (int)(formY + tid * 10);
-  if (tid >= 32 && tid < 62) digit_rows[(tid - 32) / 6][(tid - 32) % 6] = 0;
-  __syncthreads();
-  // score, :403, 480-525: character i at x = 10 + 6 i, rows 10..14
-  if (tid < 5) score_row_mask(digit_rows[tid], score, tid, 10, 6, false);
-  const int x0 = alien_x[0], y0 = alien_y[0];
+  auto alien_x = [&](int col) { return (int)(formX + col * 12); };
+  auto alien_y = [&](int row) { return (int)(formY + row * 10); };
+  const int x0 = (int)formX, y0 = (int)formY;
+  // 64 bits of the blank-row mask from the 32-row group of this workgroup's first row on; a workgroup whose rows
+  // reach beyond them takes every row for painted
+  const int y_lo = max(c_first, 0) / kChunksPerRow, y_hi = (c_end - 1) / kChunksPerRow, mask_base = y_lo & ~31;
+  const uint32_t* mask_words = rec + InvadersGame::kRowMaskAt + (y_lo >> 5);
+  const uint64_t painted_rows = y_hi - mask_base < 64 ? (uint64_t)mask_words[0] | ((uint64_t)mask_words[1] << 32) : ~0ull;
+  // the score rows 10..14 are chunks 300..449: only a workgroup that covers some of them builds their masks
+  // (:403, 480-525: character i at x = 10 + 6 i)
+  if (c_first < 15 * kChunksPerRow && c_end > 10 * kChunksPerRow) {
+    if (tid < 30) digit_rows[tid / 6][tid % 6] = 0;
+    __syncthreads();
+    if (tid < 5) score_row_mask(digit_rows[tid], score, tid, 10, 6, false);
+    __syncthreads();
+  }
   // alien sprite rows, bit dx = column dx: .X..X. / ..XX.. / .XXXX. / XX..XX / XXXXXX / .X..X. (:413-435)
   const uint64_t sprite = 0x12ull | (0x0Cull << 6) | (0x1Eull << 12) | (0x33ull << 18) | (0x3Full << 24) | (0x12ull << 30);
   // cannon rows ...XX... / ..XXXX.. / ..XXXX.. / .XXXXXX. / XXXXXXXX x2 (:437-459)
   const uint64_t cannon = 0x18ull | (0x3Cull << 8) | (0x3Cull << 16) | (0x7Eull << 24) | (0xFFull << 32) | (0xFFull << 40);
-
-  enum : uint32_t { kLayerAliens = 1, kLayerCannon = 2, kLayerPlayerBullets = 4, kLayerAlienBullets = 8, kLayerHud = 16, kLayerGround = 32 };
-  // only the rows this workgroup writes
-  for (int y = max(c_first, 0) / kChunksPerRow + tid; y <= (c_end - 1) / kChunksPerRow; y += THREADS) {
-    uint32_t f = 0;
-    // a row of the formation that still holds an alien and whose sprites cover y
-#pragma unroll
-    for (int row = 0; row < si::kRows; row++)
-      if ((unsigned)(y - alien_y[row]) < 6u && ((aliens >> (row * si::kCols)) & ((1ull << si::kCols) - 1ull)) != 0ull) f |= kLayerAliens;
-    if ((unsigned)(y - (kScreenH - 40)) < 6u) f |= kLayerCannon;
-#pragma unroll
-    for (int b = 0; b < si::kMaxPB; b++)
-      if (b < npb && (unsigned)(y - pby[b]) < 4u) f |= kLayerPlayerBullets;
-#pragma unroll
-    for (int b = 0; b < si::kMaxAB; b++)
-      if (b < nab && (unsigned)(y - aby[b]) < 4u) f |= kLayerAlienBullets;
-    if ((unsigned)(y - 10) < 6u) f |= kLayerHud;
-    if ((unsigned)(y - (kScreenH - 20)) < 2u) f |= kLayerGround;
-    row_layers[y] = (uint8_t)f;
-  }
-  __syncthreads();
 
   // One 16-byte chunk per lane and iteration (gx_frame.h: the bytes of the six pixels p0 .. p0 + 5 of a row).
   // Per layer a lane builds the 6-bit mask of the window's pixels the layer paints, spreads it to byte
@@ -335,9 +350,21 @@ __global__ void __launch_bounds__(THREADS) invaders_raster_kernel(StepArgs a, ui
   for (int c = c_first + tid; c < c_end; c += THREADS) {
     if (c < 0) continue;
     const int y = c / kChunksPerRow, j = c - y * kChunksPerRow;
-    const uint32_t layers = row_layers[y];
     uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (layers != 0u) {
+    if ((painted_rows >> ((y - mask_base) & 63)) & 1ull) {
+      // Which layers touch this row.  Row origins of the formation are 9..11 apart and a sprite is 6 tall, so the one
+      // row of aliens whose sprites can cover y is floor((y - y0 + 1) / 10).
+      int row = ((y - y0 + 1) * 205) >> 11;  // / 10, exact below 1024
+      row = row > si::kRows - 1 ? si::kRows - 1 : (row < 0 ? 0 : row);
+      const int dy_alien = y - alien_y(row);
+      const bool in_aliens = (unsigned)dy_alien < 6u && ((aliens >> (row * si::kCols)) & ((1ull << si::kCols) - 1ull)) != 0ull;
+      const bool in_cannon = (unsigned)(y - (kScreenH - 40)) < 6u;
+      bool in_pb = false, in_ab = false;
+#pragma unroll
+      for (int b = 0; b < si::kMaxPB; b++) in_pb = in_pb || (b < npb && (unsigned)(y - pby[b]) < 4u);
+#pragma unroll
+      for (int b = 0; b < si::kMaxAB; b++) in_ab = in_ab || (b < nab && (unsigned)(y - aby[b]) < 4u);
+      const bool in_hud = (unsigned)(y - 10) < 6u, in_ground = (unsigned)(y - (kScreenH - 20)) < 2u;
       const int p0 = (16 * j) / 3, ph = j % 3;
       const uint32_t sh8 = 8u * (uint32_t)ph;
       // mask: bit q set = pixel p0 + q takes the colour rgb (r | g << 8 | b << 16)
@@ -355,45 +382,41 @@ __global__ void __launch_bounds__(THREADS) invaders_raster_kernel(StepArgs a, ui
         const int sh = left - p0;
         return sh >= 6 || sh <= -32 ? 0u : (sh >= 0 ? bits << sh : bits >> -sh) & 63u;
       };
-      // aliens, :361-385.  Row origins are 9..11 apart and a sprite is 6 tall, so the row whose sprite can cover
-      // y is floor((y - y0 + 1) / 10); columns are 11..13 apart and 6 wide, so a sprite that meets the window
-      // covers its first or its last pixel, and the column of a pixel x is floor((x - x0 + 1) / 12).
-      if (layers & kLayerAliens) {
-        int row = ((y - y0 + 1) * 205) >> 11;  // / 10, exact below 1024
-        row = row > si::kRows - 1 ? si::kRows - 1 : (row < 0 ? 0 : row);
-        const int dy = y - alien_y[row];
-        if ((unsigned)dy < 6u) {
-          const uint32_t bits = (uint32_t)(sprite >> (6 * dy)) & 63u;
+      // aliens, :361-385.  Columns are 11..13 apart and 6 wide, so a sprite that meets the window covers its
+      // first or its last pixel, and the column of a pixel x is floor((x - x0 + 1) / 12).
+      if (in_aliens) {
+        {
+          const uint32_t bits = (uint32_t)(sprite >> (6 * dy_alien)) & 63u;
           uint32_t m = 0;
 #pragma unroll
           for (int end = 0; end < 2; end++) {
             const int d = p0 + 5 * end - x0 + 1;
             if (d >= 0 && d < 512) {
               const int col = (d * 171) >> 11;  // / 12, exact below 512
-              if (col < si::kCols && ((aliens >> (row * si::kCols + col)) & 1ull)) m |= window(bits, alien_x[col]);
+              if (col < si::kCols && ((aliens >> (row * si::kCols + col)) & 1ull)) m |= window(bits, alien_x(col));
             }
           }
           paint(m, palette(kMagenta + (uint32_t)row));  // magenta, cyan, yellow, green, red
         }
       }
       // player cannon at ((int)playerX, 170), :388
-      if (layers & kLayerCannon) paint(window((uint32_t)(cannon >> (8 * (y - (kScreenH - 40)))) & 0xFFu, player_x), palette(kGreen));
+      if (in_cannon) paint(window((uint32_t)(cannon >> (8 * (y - (kScreenH - 40)))) & 0xFFu, player_x), palette(kGreen));
       // player bullets (yellow) then alien bullets (red), 2 x 4 pixels each, :391-400
-      if (layers & kLayerPlayerBullets) {
+      if (in_pb) {
         uint32_t m = 0;
 #pragma unroll
         for (int b = 0; b < si::kMaxPB; b++)
           if (b < npb && (unsigned)(y - pby[b]) < 4u) m |= span_bits6(pbx[b], 2, p0);
         paint(m, palette(kYellow));
       }
-      if (layers & kLayerAlienBullets) {
+      if (in_ab) {
         uint32_t m = 0;
 #pragma unroll
         for (int b = 0; b < si::kMaxAB; b++)
           if (b < nab && (unsigned)(y - aby[b]) < 4u) m |= span_bits6(abx[b], 2, p0);
         paint(m, palette(kRed));
       }
-      if (layers & kLayerHud) {
+      if (in_hud) {
         const int dy = y - 10;
         // score (white), :403
         if (dy < 5) {
@@ -416,7 +439,7 @@ __global__ void __launch_bounds__(THREADS) invaders_raster_kernel(StepArgs a, ui
         paint(m, palette(kGreen));
       }
       // ground line, :407-410
-      if (layers & kLayerGround) paint(63u, palette(kGreen));
+      if (in_ground) paint(63u, palette(kGreen));
     }
     frame[c] = v;
   }
@@ -424,26 +447,20 @@ __global__ void __launch_bounds__(THREADS) invaders_raster_kernel(StepArgs a, ui
 
 hipError_t launch_invaders_step(const StepArgs& a, int policy, dim3 grid, hipStream_t stream) { return launch_frame_step<InvadersGame>(a, policy, grid, stream); }
 hipError_t launch_invaders_reset(const StepArgs& a, dim3 grid, hipStream_t stream) { return launch_frame_reset<InvadersGame>(a, grid, stream); }
+static_assert(InvadersGame::kRecordDwords * 4 == kInvadersRecordBytes, "the render records are allocated by this size");
+hipError_t launch_invaders_pack(const StepArgs& a, dim3 grid, hipStream_t stream) { return launch_frame_pack<InvadersGame>(a, grid, stream); }
 hipError_t launch_invaders_raster(const StepArgs& a, uint8_t* frames, hipStream_t stream) {
   if (a.num_envs == 0) return hipSuccess;
-  // Three consecutive one-wave workgroups per frame, 33 steps each: 1.19 ms at 65 536 envs (step + raster) against
-  // 1.22 for one 256-thread workgroup per frame, 1.20 for 64 x 4, 1.22 for 128 x 2; five or more workgroups per
-  // frame lose to the prologue every workgroup repeats (twenty state loads, three LDS tables, two barriers):
-  // 64 x 5 1.54, 64 x 9 1.96.
-  // Tuning aid: GYMX_FRAME_RASTER=<threads>,<workgroups per frame>, threads 64, 128 or 256.
-  static int threads = 64, split = 3;
-  static const bool parsed = [] {
-    const char* s = std::getenv("GYMX_FRAME_RASTER");
-    int t = 0, sp = 0;
-    if (s && std::sscanf(s, "%d,%d", &t, &sp) == 2 && (t == 64 || t == 128 || t == 256) && sp >= 1 && sp <= 128) { threads = t; split = sp; }
-    return true;
-  }();
-  (void)parsed;
-  const dim3 grid((unsigned)(a.num_envs * (uint64_t)split));
-  if (threads == 64) hipLaunchKernelGGL(invaders_raster_kernel<64>, grid, dim3(64), 0, stream, a, frames, split);
-  else if (threads == 128) hipLaunchKernelGGL(invaders_raster_kernel<128>, grid, dim3(128), 0, stream, a, frames, split);
-  else hipLaunchKernelGGL(invaders_raster_kernel<256>, grid, dim3(256), 0, stream, a, frames, split);
-  return hipGetLastError();
+  // Nine four-wave workgroups per frame, three 4 KiB steps each.  Measured at 65 536 envs (step + raster, ms):
+  // 256 x 9 1.059, x 11 1.08, x 7 1.09, x 6 1.12, x 10 1.18, x 12 1.24; 128 x 18 1.062, x 17 1.065, x 16 1.075,
+  // x 20 1.11; 64 x 34 1.074; two steps per wave 1.23-1.46: this raster spends about 50 vector and as many scalar
+  // instructions per 16-byte store, twice what the other two do, and the shorter a wave the more its set-up weighs.
+  static const RasterShape shape = raster_shape_from_env("GYMX_FRAME_RASTER", RasterShape{256, 9}, 256);
+  return launch_raster_slices(a.num_envs, shape.threads, shape.split, [&](dim3 grid, const RasterLaunch& g) {
+    if (shape.threads == 64) hipLaunchKernelGGL(invaders_raster_kernel<64>, grid, dim3(64), 0, stream, a, frames, g);
+    else if (shape.threads == 128) hipLaunchKernelGGL(invaders_raster_kernel<128>, grid, dim3(128), 0, stream, a, frames, g);
+    else hipLaunchKernelGGL(invaders_raster_kernel<256>, grid, dim3(256), 0, stream, a, frames, g);
+  });
 }
 hipError_t launch_invaders_sample(const StepArgs& a, void* out, dim3 grid, hipStream_t stream) { return launch_frame_sample<InvadersGame>(a, out, grid, stream); }
 

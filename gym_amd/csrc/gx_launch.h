@@ -51,19 +51,26 @@ hipError_t launch_blackjack_sample(const StepArgs& a, void* out, dim3 grid, hipS
 // Pong (gx_pong.hip)
 hipError_t launch_pong_step(const StepArgs& a, int policy, dim3 grid, hipStream_t stream);
 hipError_t launch_pong_reset(const StepArgs& a, dim3 grid, hipStream_t stream);
+// a.render: the records the step / reset / pack kernels of the game wrote
 hipError_t launch_pong_raster(const StepArgs& a, uint8_t* frames, hipStream_t stream);
+hipError_t launch_pong_pack(const StepArgs& a, dim3 grid, hipStream_t stream);
+constexpr size_t kPongRecordBytes = 32;
 hipError_t launch_pong_sample(const StepArgs& a, void* out, dim3 grid, hipStream_t stream);
 
 // Breakout (gx_breakout.hip)
 hipError_t launch_breakout_step(const StepArgs& a, int policy, dim3 grid, hipStream_t stream);
 hipError_t launch_breakout_reset(const StepArgs& a, dim3 grid, hipStream_t stream);
 hipError_t launch_breakout_raster(const StepArgs& a, uint8_t* frames, hipStream_t stream);
+hipError_t launch_breakout_pack(const StepArgs& a, dim3 grid, hipStream_t stream);
+constexpr size_t kBreakoutRecordBytes = 64;
 hipError_t launch_breakout_sample(const StepArgs& a, void* out, dim3 grid, hipStream_t stream);
 
 // SpaceInvaders (gx_invaders.hip)
 hipError_t launch_invaders_step(const StepArgs& a, int policy, dim3 grid, hipStream_t stream);
 hipError_t launch_invaders_reset(const StepArgs& a, dim3 grid, hipStream_t stream);
 hipError_t launch_invaders_raster(const StepArgs& a, uint8_t* frames, hipStream_t stream);
+hipError_t launch_invaders_pack(const StepArgs& a, dim3 grid, hipStream_t stream);
+constexpr size_t kInvadersRecordBytes = 128;
 hipError_t launch_invaders_sample(const StepArgs& a, void* out, dim3 grid, hipStream_t stream);
 
 // host path of small batches (gx_hostpath.hip)

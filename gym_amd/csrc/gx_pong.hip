@@ -116,6 +116,13 @@ struct PongGame {
     pong_step(s, action, key, env, reward, done);
   }
   static __device__ __forceinline__ int32_t steps(const State& s) { return s.steps; }
+  // the ball's corner, the paddles' tops ((int) casts truncate toward zero, Envs.Pong.cs:173-179), the two scores
+  static constexpr int kRecordDwords = 8;
+  static __device__ __forceinline__ void pack(const State& s, uint32_t* record) {
+    int4* out = reinterpret_cast<int4*>(record);
+    out[0] = make_int4((int)s.ballX, (int)s.ballY, (int)s.leftPaddleY, (int)s.rightPaddleY);
+    out[1] = make_int4(s.leftScore, s.rightScore, 0, 0);
+  }
 };
 
 // One 16-byte store per lane.  A frame is 6300 chunks of 16 bytes, a row 30 of them;
@@ -127,23 +134,15 @@ struct PongGame {
 // on the frame buffer's own THREADS x 16-byte grid -- the first and the last step of a frame partly masked --
 // and every wave's 1 KiB store lies within one aligned block.
 template <int THREADS>
-__global__ void __launch_bounds__(THREADS) pong_raster16_kernel(StepArgs a, uint8_t* __restrict__ frames, int split) {
+__global__ void __launch_bounds__(THREADS) pong_raster16_kernel(StepArgs a, uint8_t* __restrict__ frames, RasterLaunch g) {
   __shared__ uint32_t digit_rows[5][6];  // rows 20..24 as 160-bit masks, plus a zero word for the 64-bit window
-  // the parts of a frame are consecutive workgroups: workgroups in flight together write neighbouring memory
-  const uint64_t env = blockIdx.x / (uint32_t)split;
-  const int part = (int)(blockIdx.x % (uint32_t)split);
-  constexpr int kChunksPerRow = kScreenW * 3 / 16, kChunks = kFrameBytes / 16;
-  const int head = (int)((env * (uint64_t)kChunks) & (THREADS - 1));
-  const int nsteps = (head + kChunks + THREADS - 1) / THREADS;
-  const int per_part = (nsteps + split - 1) / split;
-  const int step0 = part * per_part, step1 = min(nsteps, step0 + per_part);
-  if (step0 >= step1) return;
-  const int c_first = step0 * THREADS - head, c_end = min(kChunks, step1 * THREADS - head);
+  constexpr int kChunksPerRow = kScreenW * 3 / 16;
+  uint64_t env;
+  int c_first, c_end;
+  if (!raster_part<THREADS>(g, env, c_first, c_end)) return;
 
-  const double* r = static_cast<const double*>(a.state_real);
-  // (int) casts truncate toward zero, Envs.Pong.cs:173-179
-  const int bx = (int)r[env], by = (int)r[a.stride + env];
-  const int ly = (int)r[4 * a.stride + env], ry = (int)r[5 * a.stride + env];
+  const uint32_t* rec = a.render + env * PongGame::kRecordDwords;
+  const int bx = (int)rec[0], by = (int)rec[1], ly = (int)rec[2], ry = (int)rec[3];
   // the score rows 20..24 are chunks 600..749: only a workgroup that covers some of them builds their masks
   if (c_first < 25 * kChunksPerRow && c_end > 20 * kChunksPerRow) {
     if (threadIdx.x < 30) digit_rows[threadIdx.x / 6][threadIdx.x % 6] = 0;
@@ -151,7 +150,7 @@ __global__ void __launch_bounds__(THREADS) pong_raster16_kernel(StepArgs a, uint
     if (threadIdx.x < 10) {
       // Envs.Pong.cs:211-251: decimal string centred on centerX, digit i at startX + 8 i, rows 20..24
       const int side = threadIdx.x / 5, row = threadIdx.x % 5;
-      const int score = a.state_int[(uint64_t)side * a.stride + env];
+      const int score = (int)rec[4 + side];
       score_row_mask(digit_rows[row], score, row, side ? 3 * kScreenW / 4 : kScreenW / 4, 8, true);
     }
     __syncthreads();
@@ -196,28 +195,24 @@ __global__ void __launch_bounds__(THREADS) pong_raster16_kernel(StepArgs a, uint
 
 hipError_t launch_pong_step(const StepArgs& a, int policy, dim3 grid, hipStream_t stream) { return launch_frame_step<PongGame>(a, policy, grid, stream); }
 hipError_t launch_pong_reset(const StepArgs& a, dim3 grid, hipStream_t stream) { return launch_frame_reset<PongGame>(a, grid, stream); }
+static_assert(PongGame::kRecordDwords * 4 == kPongRecordBytes, "the render records are allocated by this size");
+hipError_t launch_pong_pack(const StepArgs& a, dim3 grid, hipStream_t stream) { return launch_frame_pack<PongGame>(a, grid, stream); }
 hipError_t launch_pong_raster(const StepArgs& a, uint8_t* frames, hipStream_t stream) {
   if (a.num_envs == 0) return hipSuccess;
-  // Ten consecutive four-wave workgroups per frame, three 4 KiB steps each (the tenth workgroup of a frame finds
-  // nothing left and retires).  Measured at 65 536 envs (step + raster, ms): one 256-thread workgroup walking a
-  // whole frame 1.21; 64 threads x 10..25 workgroups per frame 1.20; three steps per wave: 64 x 34 and 128 x 17
-  // 1.09, 256 x 9 1.06, 256 x 10 1.04, 512 x 5 1.07; two steps (64 x 50, 128 x 25) 1.35; four (256 x 8) 1.37.
-  // Tuning aid: GYMX_PONG_RASTER=<threads>,<workgroups per frame>, threads 64, 128, 256, 512 or 1024.
-  static int threads = 256, split = 10;
-  static const bool parsed = [] {
-    const char* s = std::getenv("GYMX_PONG_RASTER");
-    int t = 0, sp = 0;
-    if (s && std::sscanf(s, "%d,%d", &t, &sp) == 2 && (t == 64 || t == 128 || t == 256 || t == 512 || t == 1024) && sp >= 1 && sp <= 128) { threads = t; split = sp; }
-    return true;
-  }();
-  (void)parsed;
-  const dim3 grid((unsigned)(a.num_envs * (uint64_t)split));
-  if (threads == 64) hipLaunchKernelGGL(pong_raster16_kernel<64>, grid, dim3(64), 0, stream, a, frames, split);
-  else if (threads == 128) hipLaunchKernelGGL(pong_raster16_kernel<128>, grid, dim3(128), 0, stream, a, frames, split);
-  else if (threads == 512) hipLaunchKernelGGL(pong_raster16_kernel<512>, grid, dim3(512), 0, stream, a, frames, split);
-  else if (threads == 1024) hipLaunchKernelGGL(pong_raster16_kernel<1024>, grid, dim3(1024), 0, stream, a, frames, split);
-  else hipLaunchKernelGGL(pong_raster16_kernel<256>, grid, dim3(256), 0, stream, a, frames, split);
-  return hipGetLastError();
+  // 28 two-wave workgroups per frame, two 2 KiB steps each (a frame is 50 or 51 such steps: the last two or three
+  // workgroups of a frame find nothing left and retire).  Measured at 65 536 envs (step + raster, ms): 128 x 28
+  // 0.932, x 30 0.946, x 26 0.949, x 25 1.00; 256 x 14 0.938, x 13 0.950, x 12 1.01; 512 x 7 0.955; 64 x 34 0.97;
+  // three steps per wave 1.01-1.04, one 256-thread workgroup walking a whole frame 1.2.  One-wave workgroups of two
+  // steps would need more than 2.4 million workgroups a millisecond, which is the rate this grid is dealt at
+  // (64 x 50 1.39, x 66 1.83, x 99 2.75).
+  static const RasterShape shape = raster_shape_from_env("GYMX_PONG_RASTER", RasterShape{128, 28}, 1024);
+  return launch_raster_slices(a.num_envs, shape.threads, shape.split, [&](dim3 grid, const RasterLaunch& g) {
+    if (shape.threads == 64) hipLaunchKernelGGL(pong_raster16_kernel<64>, grid, dim3(64), 0, stream, a, frames, g);
+    else if (shape.threads == 128) hipLaunchKernelGGL(pong_raster16_kernel<128>, grid, dim3(128), 0, stream, a, frames, g);
+    else if (shape.threads == 512) hipLaunchKernelGGL(pong_raster16_kernel<512>, grid, dim3(512), 0, stream, a, frames, g);
+    else if (shape.threads == 1024) hipLaunchKernelGGL(pong_raster16_kernel<1024>, grid, dim3(1024), 0, stream, a, frames, g);
+    else hipLaunchKernelGGL(pong_raster16_kernel<256>, grid, dim3(256), 0, stream, a, frames, g);
+  });
 }
 hipError_t launch_pong_sample(const StepArgs& a, void* out, dim3 grid, hipStream_t stream) { return launch_frame_sample<PongGame>(a, out, grid, stream); }
 
