@@ -152,7 +152,12 @@ __device__ __forceinline__ bool raster_part(const RasterLaunch& g, uint64_t& env
 template <class F>
 hipError_t launch_raster_slices(uint64_t num_envs, int threads, int split, F&& launch) {
   const int steps = (kFrameBytes / 16 + threads - 1) / threads;
-  constexpr uint64_t kSlice = 8ull * 65535ull;
+  // GYMX_RASTER_SLICE=<frames>: a smaller slice, so that tests reach the several-launch path with small batches
+  static const uint64_t kSlice = [] {
+    const char* e = std::getenv("GYMX_RASTER_SLICE");
+    const long long v = e ? std::atoll(e) : 0;
+    return v >= 1 && v <= 8ll * 65535ll ? (uint64_t)v : 8ull * 65535ull;
+  }();
   for (uint64_t first = 0; first < num_envs; first += kSlice) {
     const uint64_t count = num_envs - first < kSlice ? num_envs - first : kSlice;
     RasterLaunch g{first, (uint32_t)count, (uint32_t)((count + 7) / 8), {(steps + split - 1) / split, (steps + split) / split}};

@@ -732,3 +732,40 @@ def test_sampled_actions_replay_the_in_kernel_policy(oracle, env_id):
         assert np.array_equal(bits(dev[:n].cpu().numpy()), bits(oa)), t
         ar, ai = a.get_state(); br, bi = b.get_state()
         assert np.array_equal(ai, bi) and np.array_equal(bits(ar), bits(br)), t
+
+
+_FRAME_DIGEST = r"""
+import hashlib, sys
+sys.path.insert(0, %r)
+from gym_amd import _lib as L
+from gym_amd.engine import Context, DeviceBatch
+ctx = Context(0)
+for env_id in (L.ENV_PONG, L.ENV_BREAKOUT, L.ENV_SPACEINVADERS):
+    v = DeviceBatch(ctx, env_id, 101, seed=12, flags=L.AUTORESET)
+    v.reset()
+    h = hashlib.sha256(v.get_obs().tobytes())
+    for _ in range(40):
+        v.step_random()
+    v.wait()
+    h.update(v.get_obs().tobytes())
+    print(h.hexdigest())
+    v.close()
+ctx.close()
+"""
+
+
+def test_frames_of_a_batch_rastered_in_several_launches():
+    '''a batch beyond what one raster grid holds (524 280 frames) is rastered slice by slice; with the slice set to
+    24 frames a batch of 101 takes five launches, the last one short, and must give the frames one launch gives'''
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    def digests(slice_frames):
+        env = dict(os.environ)
+        env.pop("GYMX_RASTER_SLICE", None)
+        if slice_frames:
+            env["GYMX_RASTER_SLICE"] = str(slice_frames)
+        r = subprocess.run([sys.executable, "-c", _FRAME_DIGEST % root], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return r.stdout.split()
+    whole, sliced = digests(0), digests(24)
+    assert len(whole) == 3 and whole == sliced
