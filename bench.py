@@ -114,8 +114,10 @@ B_ALG = {
     "pong": 60 + 60 + 4 + 4 + 4 + 4 + 1 + 100800,          # 100937
     "breakout": 72 + 72 + 4 + 4 + 4 + 4 + 1 + 100800,      # 100961
     "spaceinvaders": 140 + 140 + 4 + 4 + 4 + 4 + 1 + 100800,  # 101097
-    # observation index r+w, steps r+w, ep_return r+w, action, reward, done; --blackjack-full adds the face-down row r+w
-    "blackjack": 4 + 4 + 4 + 4 + 4 + 4 + 4 + 4 + 1,       # 33
+    # observation index r+w, steps r+w, ep_return r+w, reward, done.  The reference's Step ignores its action
+    # (Envs.Blackjack.cs:35-37) and so does the kernel: the action row is never read (FETCH_SIZE agrees: 12 B per
+    # env).  --blackjack-full (upstream's rules) adds the action and the face-down row r+w.
+    "blackjack": 4 + 4 + 4 + 4 + 4 + 4 + 4 + 1,           # 29
 }
 # binary64 mode: the state rows double in width (read + write), nothing else changes
 B_ALG_FP64_EXTRA = {"cartpole": 32, "mountaincar": 16, "mountaincarcontinuous": 16, "pendulum": 24, "acrobot": 48}
@@ -353,7 +355,11 @@ def main():
         # f64 state r+w, steps r+w, reward, done, derived f32 observation rows
         b_alg = 32 + 32 + 4 + 4 + 4 + 1 + 24
     else:
-        b_alg = B_ALG[args.env] - (4 if args.policy == "random" else 0) + (8 if args.taxi_full or args.blackjack_full else 0)
+        b_alg = B_ALG[args.env] + (8 if args.taxi_full or args.blackjack_full else 0)
+        if args.env == "blackjack":
+            b_alg += 4 if args.blackjack_full and args.policy != "random" else 0  # only upstream's rules look at the action
+        elif args.policy == "random":
+            b_alg -= 4
         if fp64_state:
             b_alg += B_ALG_FP64_EXTRA[args.env]
     if k_roll > 1:

@@ -260,7 +260,8 @@ struct InvadersGame {
     out[4] = make_int4((int)s.abx[0], (int)s.abx[1], (int)s.aby[0], (int)s.aby[1]);
     // dwords 20-27: bit y set = something can touch frame row y (most rows are blank), the eighth dword zero
     uint32_t m[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-    auto add_rows = [&](int first, int count) {  // count <= 6
+    auto add_rows = [&](int first, int count) {  // count <= 6; any first (a written state may hold anything)
+      first = first < -64 ? -64 : (first > 512 ? 512 : first);
 #pragma unroll
       for (int d = 0; d < 7; d++) {
         int lo = first - 32 * d, hi = lo + count;
