@@ -637,6 +637,7 @@ extern "C" int gx_vec_create(gx_ctx* ctx, const gx_desc* desc, gx_vec** out) {
   if (v->is_tabular && env != GX_ENV_DUMMY && !v->is_blackjack) {
     int rc = build_table(v, table);
     if (rc != GX_OK) { gx_vec_destroy(v); return rc; }
+    table.resize((table.size() + 3) & ~(size_t)3, 0);  // the kernels stage it in 16-byte pieces
     VEC_TRY(hipMalloc((void**)&v->d_table, table.size() * 4));
     VEC_TRY(hipMemcpy(v->d_table, table.data(), table.size() * 4, hipMemcpyHostToDevice));
     // stage in LDS when it fits in 64 KiB, else the kernel reads the table through L2

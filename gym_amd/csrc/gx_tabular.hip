@@ -65,12 +65,22 @@ __device__ __forceinline__ int32_t tabular_reset_state(int32_t start_state, cons
 // twenty registers, hence a variant of its own).
 template <int POLICY, bool LDS_TABLE, bool SLIP, bool MULTI, bool ALIGNED>
 __global__ void __launch_bounds__(kTabularBlock) tabular_step_kernel(StepArgs a) {
-  extern __shared__ uint32_t lds_table[];
+  extern __shared__ __align__(16) uint32_t lds_table[];
   const int A = a.table_actions, ncols = A + 1, O = SLIP ? 3 : 1;
   const int entries = a.table_states * ncols * O;
   const uint32_t* tab = a.table;
   if (LDS_TABLE) {
-    for (int i = threadIdx.x; i < entries + 8; i += blockDim.x) lds_table[i] = a.table[i];
+    if (POLICY == GX_POLICY_DEVICE_ACTIONS) {
+      // sixteen bytes per lane and trip (the device copy of the table is padded to a multiple of four words): at
+      // 64 Mi envs the Taxi stub steps in 0.283 instead of 0.303 ms, full Taxi-v3 in 0.402 instead of 0.413, the
+      // 8x8 FrozenLake in 0.278 instead of 0.285
+      const int chunks = (entries + 8 + 3) >> 2;
+      for (int i = threadIdx.x; i < chunks; i += blockDim.x)
+        reinterpret_cast<uint4*>(lds_table)[i] = reinterpret_cast<const uint4*>(a.table)[i];
+    } else {
+      // with the actions sampled in the kernel the word-by-word copy is the faster one by 1-1.5 % (same runs)
+      for (int i = threadIdx.x; i < entries + 8; i += blockDim.x) lds_table[i] = a.table[i];
+    }
     __syncthreads();
     tab = lds_table;
   }
