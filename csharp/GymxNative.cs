@@ -97,6 +97,7 @@ internal static unsafe partial class Native
     [LibraryImport(Lib)] internal static partial int gx_vec_reset(IntPtr vec);
     [LibraryImport(Lib)] internal static partial int gx_vec_get_state(IntPtr vec, void* hostSoa, nuint bytes);
     [LibraryImport(Lib)] internal static partial int gx_vec_set_state(IntPtr vec, void* hostSoa, nuint bytes);
+    [LibraryImport(Lib)] internal static partial int gx_vec_set_rng_draws(IntPtr vec, double* u, nuint count);
     [LibraryImport(Lib)] internal static partial int gx_vec_get_obs(IntPtr vec, void* hostObs, nuint bytes);
     [LibraryImport(Lib)] internal static partial int gx_vec_step_async(IntPtr vec, void* hActions, void* hObs, void* hReward, byte* hDone, byte* hTruncated);
     [LibraryImport(Lib)] internal static partial int gx_vec_wait(IntPtr vec);

@@ -88,6 +88,7 @@ SIGNATURES = {
     "gx_vec_reset": (_i, [_vp]),
     "gx_vec_get_state": (_i, [_vp, _vp, C.c_size_t]),
     "gx_vec_set_state": (_i, [_vp, _vp, C.c_size_t]),
+    "gx_vec_set_rng_draws": (_i, [_vp, _vp, C.c_size_t]),
     "gx_vec_get_obs": (_i, [_vp, _vp, C.c_size_t]),
     "gx_vec_step_async": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "gx_vec_wait": (_i, [_vp]),

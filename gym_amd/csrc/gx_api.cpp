@@ -83,6 +83,8 @@ struct gx_vec {
   uint8_t* d_frames = nullptr;
   uint32_t* d_render = nullptr;  // frame envs: one packed record per env between the step and the raster
   uint32_t* d_table = nullptr;
+  double* d_forced = nullptr;   // Pong: [2][stride] caller-supplied uniforms (gx_vec_set_rng_draws), allocated on first use
+  bool forced_pending = false;  // the next step or reset launch hands d_forced to its kernel, once
   uint32_t* d_error = nullptr;
   void* d_actions = nullptr;  // staging for the host path
   uint32_t* h_error = nullptr;  // pinned
@@ -493,6 +495,7 @@ StepArgs make_args(const gx_vec* v, const void* d_actions, int k_steps, uint64_t
   a.step_limit = v->step_limit;
   a.derive_returns = v->derive_returns ? 1 : 0;
   a.ret_per_step = v->ret_per_step;
+  a.forced_draws = v->forced_pending ? v->d_forced : nullptr;
   return a;
 }
 
@@ -529,6 +532,7 @@ int launch_step(gx_vec* v, const void* d_actions, int k_steps, uint64_t action_s
   }
   if (e != hipSuccess) return fail(GX_ERR_HIP, "step kernel launch failed: %s", hipGetErrorString(e));
   v->tick += (uint64_t)k_steps;
+  v->forced_pending = false;
   v->state_dirty = false;
   v->sweep_parity ^= 1u;
   v->last_stream = stream;
@@ -573,7 +577,7 @@ extern "C" int gx_vec_destroy(gx_vec* v) {
     (void)hipStreamSynchronize(v->ctx->copy);
   }
   void* dev[] = {v->d_real, v->d_int, v->d_reward, v->d_done, v->d_trunc, v->d_ep_return, v->d_ep_length,
-                 v->d_slots, v->d_obs, v->d_frames, v->d_render, v->d_table, v->d_error, v->d_actions};
+                 v->d_slots, v->d_obs, v->d_frames, v->d_render, v->d_table, v->d_error, v->d_actions, v->d_forced};
   for (void* p : dev)
     if (p) (void)hipFree(p);
   if (v->h_error) (void)hipHostFree(v->h_error);
@@ -791,6 +795,7 @@ extern "C" int gx_vec_reset(gx_vec* v) {
     if (e == hipSuccess) e = frame_raster(v, a, c->compute);
   }
   if (e != hipSuccess) return fail(GX_ERR_HIP, "reset kernel launch failed: %s", hipGetErrorString(e));
+  v->forced_pending = false;
   v->tick += 1;
   HIP_TRY(hipStreamSynchronize(c->compute));
   return GX_OK;
@@ -856,6 +861,37 @@ extern "C" int gx_vec_set_state(gx_vec* v, const void* host, size_t bytes) {
   if (v->is_acrobot64) HIP_TRY(launch_acrobot64_reset(a, 1, v->grid, c->compute));
   if (v->acrobot_angles) HIP_TRY(launch_classic_derive(v->classic_id, a, v->grid, c->compute));
   HIP_TRY(hipStreamSynchronize(c->compute));
+  return GX_OK;
+}
+
+extern "C" int gx_vec_set_rng_draws(gx_vec* v, const double* u, size_t count) {
+  if (!v) return fail(GX_ERR_INVALID, "gx_vec_set_rng_draws: null batch");
+  if (v->desc.env_id != GX_ENV_PONG)
+    return fail(GX_ERR_UNSUPPORTED, "gx_vec_set_rng_draws: env id %d; only Pong draws inside Step (its ball reset) -- replay the other envs with gx_vec_set_state", v->desc.env_id);
+  if (!u || count == 0) {  // withdraw draws that were set and not used yet
+    v->forced_pending = false;
+    return GX_OK;
+  }
+  if (count != 2 * (size_t)v->n)
+    return fail(GX_ERR_INVALID, "gx_vec_set_rng_draws: %zu values, expected 2 x %llu ([2][num_envs])", count, (unsigned long long)v->n);
+  for (size_t i = 0; i < count; i++)
+    if (!(u[i] >= 0.0 && u[i] < 1.0))  // Random.NextDouble() is in [0, 1); NaN fails the test too
+      return fail(GX_ERR_INVALID, "gx_vec_set_rng_draws: value %zu is %g, outside [0, 1)", i, u[i]);
+  gx_ctx* c = v->ctx;
+  HIP_TRY(hipSetDevice(c->device));
+  if (!v->d_forced) {
+    hipError_t e = hipMalloc((void**)&v->d_forced, (size_t)2 * v->stride * sizeof(double));
+    if (e != hipSuccess) {
+      v->d_forced = nullptr;
+      return fail(e == hipErrorOutOfMemory ? GX_ERR_OOM : GX_ERR_HIP, "gx_vec_set_rng_draws: hipMalloc failed: %s", hipGetErrorString(e));
+    }
+  }
+  HIP_TRY(hipStreamSynchronize(c->compute));  // a launch that still reads the previous draws
+  if (v->last_stream && v->last_stream != c->compute) HIP_TRY(hipStreamSynchronize(v->last_stream));
+  int rc = copy_rows(v->d_forced, u, sizeof(double), 2, v->n, v->stride, v->n, hipMemcpyHostToDevice, c->copy);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(c->copy));
+  v->forced_pending = true;
   return GX_OK;
 }
 

@@ -154,6 +154,7 @@ struct BreakoutGame {
   using State = bk::State;
   static constexpr int kActions = 4;  // Discrete(4), Envs.Breakout.cs:44
   static __device__ __forceinline__ void load(const StepArgs& a, uint64_t i, State& s) { bk::load(a, i, s); }
+  static __device__ __forceinline__ void prime(const StepArgs&, uint64_t, State&) {}
   static __device__ __forceinline__ void store(const StepArgs& a, uint64_t i, const State& s) { bk::store(a, i, s); }
   static __device__ __forceinline__ void reset(State& s, const RngKey&, uint64_t) { bk::reset(s); }
   static __device__ __forceinline__ void step(State& s, int action, const RngKey& key, uint64_t env, float& reward, bool& done) {

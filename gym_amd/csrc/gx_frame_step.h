@@ -3,6 +3,7 @@
 // and auto-reset applied as in the other kernels.  A game supplies
 //   struct G { struct State; static constexpr int kActions;
 //              static void load(const StepArgs&, uint64_t i, State&); static void store(...);
+//              static void prime(const StepArgs&, uint64_t i, State&);   // caller-supplied draws, where a game takes them
 //              static void reset(State&, const RngKey&, uint64_t env);
 //              static void step(State&, int action, const RngKey&, uint64_t env, float& reward, bool& done);
 //              static int32_t steps(const State&);
@@ -25,6 +26,7 @@ __global__ void __launch_bounds__(kBlock) frame_step_kernel(StepArgs a) {
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < a.num_envs; i += (uint64_t)gridDim.x * kBlock) {
     typename G::State s;
     G::load(a, i, s);
+    G::prime(a, i, s);
     int32_t ep_ret = 0, ep_len = 0;
     if (record) {
       ep_ret = static_cast<const int32_t*>(a.ep_return)[i];
@@ -82,6 +84,7 @@ __global__ void __launch_bounds__(kBlock) frame_reset_kernel(StepArgs a) {
   const RngKey key = make_key(a.seed_lo, a.seed_hi, a.tick);
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < a.num_envs; i += (uint64_t)gridDim.x * kBlock) {
     typename G::State s;
+    G::prime(a, i, s);
     G::reset(s, key, a.env_index_base + i);
     G::store(a, i, s);
     G::pack(s, a.render + i * G::kRecordDwords);

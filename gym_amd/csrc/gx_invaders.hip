@@ -237,6 +237,7 @@ struct InvadersGame {
   using State = si::State;
   static constexpr int kActions = 6;  // Discrete(6), Envs.SpaceInvaders.cs:47
   static __device__ __forceinline__ void load(const StepArgs& a, uint64_t i, State& s) { si::load(a, i, s); }
+  static __device__ __forceinline__ void prime(const StepArgs&, uint64_t, State&) {}
   static __device__ __forceinline__ void store(const StepArgs& a, uint64_t i, const State& s) { si::store(a, i, s); }
   static __device__ __forceinline__ void reset(State& s, const RngKey&, uint64_t) { si::reset(s); }
   static __device__ __forceinline__ void step(State& s, int action, const RngKey& key, uint64_t env, float& reward, bool& done) {

@@ -25,15 +25,27 @@ constexpr int kPaddleH = 15, kPaddleW = 2, kBallSize = 2;
 struct PongState {
   double ballX, ballY, ballVelX, ballVelY, leftPaddleY, rightPaddleY;
   int32_t leftScore, rightScore, steps;
+  // the two NextDouble() values the caller supplied for this env's next ball reset (gx_vec_set_rng_draws);
+  // force0 < 0: none, the generator is used
+  double force0 = -1.0, force1 = 0.0;
 };
 
 // Envs.Pong.cs:159-165 (stream 0 from Reset, stream 1 from inside Step)
 __device__ __forceinline__ void pong_reset_ball(PongState& p, const RngKey& key, uint64_t env, uint32_t stream) {
-  Draws d = philox_block(key, env, stream, 0);
+  double u0, u1;
+  if (p.force0 >= 0.0) {  // supplied draws serve one ball reset
+    u0 = p.force0;
+    u1 = p.force1;
+    p.force0 = -1.0;
+  } else {
+    Draws d = philox_block(key, env, stream, 0);
+    u0 = d.uniform(0);
+    u1 = d.uniform(1);
+  }
   p.ballX = kScreenW / 2.0;
   p.ballY = kScreenH / 2.0;
-  p.ballVelX = d.uniform(0) > 0.5 ? kBallSpeed : -kBallSpeed;
-  p.ballVelY = (d.uniform(1) - 0.5) * 2.0 * kBallSpeed;
+  p.ballVelX = u0 > 0.5 ? kBallSpeed : -kBallSpeed;
+  p.ballVelY = (u1 - 0.5) * 2.0 * kBallSpeed;
 }
 
 // Envs.Pong.cs:54-70
@@ -110,6 +122,12 @@ struct PongGame {
   using State = PongState;
   static constexpr int kActions = 4;  // Discrete(4), Envs.Pong.cs:36
   static __device__ __forceinline__ void load(const StepArgs& a, uint64_t i, State& s) { pong_load(a, i, s); }
+  static __device__ __forceinline__ void prime(const StepArgs& a, uint64_t i, State& s) {
+    if (a.forced_draws) {
+      s.force0 = a.forced_draws[i];
+      s.force1 = a.forced_draws[a.stride + i];
+    }
+  }
   static __device__ __forceinline__ void store(const StepArgs& a, uint64_t i, const State& s) { pong_store(a, i, s); }
   static __device__ __forceinline__ void reset(State& s, const RngKey& key, uint64_t env) { pong_reset(s, key, env); }
   static __device__ __forceinline__ void step(State& s, int action, const RngKey& key, uint64_t env, float& reward, bool& done) {

@@ -95,6 +95,15 @@ class DeviceBatch:
         buf = np.ascontiguousarray(buf, np.uint8)
         L.check(L.load().gx_vec_set_state(self._h, _ptr(buf), buf.size))
 
+    def set_rng_draws(self, u):
+        """Pong: the two NextDouble() values each env's next ball reset takes (Envs.Pong.cs:163-164), u[2][num_envs]
+        in [0, 1), for the next reset / step / rollout launch only; None withdraws draws not used yet"""
+        if u is None:
+            L.check(L.load().gx_vec_set_rng_draws(self._h, None, 0))
+            return
+        u = np.ascontiguousarray(u, np.float64)
+        L.check(L.load().gx_vec_set_rng_draws(self._h, _ptr(u), u.size))
+
     def split_state(self, buf):
         nb = self.n * self.info.n_real * np.dtype(self.real_dtype).itemsize
         reals = buf[:nb].view(self.real_dtype).reshape(self.info.n_real, self.n)

@@ -1116,14 +1116,26 @@ typedef struct {
   env_obj base;
   double ballX, ballY, ballVelX, ballVelY, leftPaddleY, rightPaddleY;
   int32_t leftScore, rightScore, steps;
+  /* recorded NextDouble() values for the next ball reset (gxo_vec_set_rng_draws); used once */
+  int forced;
+  double force0, force1;
 } pong_t;
 
 /* Envs.Pong.cs:159-165; `reset_stream` = 0 from Reset, 1 from inside Step */
 static void pong_reset_ball(pong_t* c, const rng_ctx* r, uint32_t stream) {
+  double u0, u1;
+  if (c->forced) {
+    u0 = c->force0;
+    u1 = c->force1;
+    c->forced = 0;
+  } else {
+    u0 = gxo_rng_uniform(r->seed, r->env_index, r->tick, stream, 0);
+    u1 = gxo_rng_uniform(r->seed, r->env_index, r->tick, stream, 1);
+  }
   c->ballX = SCREEN_WIDTH / 2.0;
   c->ballY = SCREEN_HEIGHT / 2.0;
-  c->ballVelX = gxo_rng_uniform(r->seed, r->env_index, r->tick, stream, 0) > 0.5 ? BALL_SPEED : -BALL_SPEED;
-  c->ballVelY = (gxo_rng_uniform(r->seed, r->env_index, r->tick, stream, 1) - 0.5) * 2.0 * BALL_SPEED;
+  c->ballVelX = u0 > 0.5 ? BALL_SPEED : -BALL_SPEED;
+  c->ballVelY = (u1 - 0.5) * 2.0 * BALL_SPEED;
 }
 
 /* Envs.Pong.cs:54-70 */
@@ -1877,11 +1889,34 @@ static void wrapped_reset(gxo_vec* v, uint64_t i, const rng_ctx* r) {
 }
 
 /* VectorEnv.cs:20-26 */
+/* Recorded draws serve one pass over the batch (one Reset or one Step of every env): what a pass did not use
+ * is dropped. */
+static void pong_drop_draws(gxo_vec* v) {
+  if (v->env_id != GXO_PONG) return;
+  for (uint64_t i = 0; i < v->n; i++) ((pong_t*)v->envs[i])->forced = 0;
+}
+
+/* u[2][N]: the two _random.NextDouble() values of env i's next ball reset (Envs.Pong.cs:58-59, 163-164), in place
+ * of the restatement's generator, for the next gxo_vec_reset or step only.  Returns -1 for another env. */
+int gxo_vec_set_rng_draws(gxo_vec* v, const double* u) {
+  if (v->env_id != GXO_PONG) return -1;
+  for (uint64_t i = 0; i < v->n; i++) {
+    pong_t* c = (pong_t*)v->envs[i];
+    c->forced = u != NULL;
+    if (u) {
+      c->force0 = u[i];
+      c->force1 = u[v->n + i];
+    }
+  }
+  return 0;
+}
+
 void gxo_vec_reset(gxo_vec* v) {
   for (uint64_t i = 0; i < v->n; i++) {
     rng_ctx r = {v->seed, v->env_index_base + i, v->tick};
     wrapped_reset(v, i, &r);
   }
+  pong_drop_draws(v);
   v->tick++;
 }
 
@@ -1945,6 +1980,7 @@ static int vec_step_impl(gxo_vec* v, const void* actions, int random_policy, voi
     if (truncated) truncated[i] = (uint8_t)trunc;
     if (d && (v->flags & GXO_AUTORESET)) wrapped_reset(v, i, &r);
   }
+  pong_drop_draws(v);
   v->tick++;
   return 0;
 }

@@ -81,6 +81,8 @@ def lib():
     L.gxo_vec_step_random.argtypes = [vp, vp, vp, vp, vp]
     L.gxo_vec_get_state.argtypes = [vp, vp]
     L.gxo_vec_set_state.argtypes = [vp, vp]
+    L.gxo_vec_set_rng_draws.argtypes = [vp, vp]
+    L.gxo_vec_set_rng_draws.restype = C.c_int
     L.gxo_vec_get_obs.argtypes = [vp, vp]
     L.gxo_vec_stats.argtypes = [vp, C.POINTER(Stats)]
     L.gxo_vec_episode_count.restype = C.c_size_t
@@ -163,6 +165,15 @@ class OracleVec:
         buf = np.ascontiguousarray(buf, dtype=np.uint8)
         assert buf.size == self.state_bytes()
         lib().gxo_vec_set_state(self._h, _ptr(buf))
+
+    def set_rng_draws(self, u):
+        """Pong: u[2][N] stands in for the generator in each env's next ball reset, for the next reset / step only"""
+        if u is None:
+            assert lib().gxo_vec_set_rng_draws(self._h, None) == 0
+            return
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        assert u.size == 2 * self.n
+        assert lib().gxo_vec_set_rng_draws(self._h, _ptr(u)) == 0
 
     def split_state(self, buf):
         """raw SoA image -> (reals [n_real, N], ints [n_int, N])"""

@@ -103,24 +103,57 @@ def record_from(engine_step, get_state_raw, get_obs, env_id, n, n_real, real_is_
     return rec
 
 
-def replay(rec, set_state_raw, step, get_state_raw, get_obs=None):
+def pong_draws_from(vel_x, vel_y):
+    """Values of `_random.NextDouble()` that Envs.Pong.cs:163-164 turns into a recorded ball velocity: (u[2][n], found[n]).
+    The direction needs any value on the right side of 0.5; the vertical speed (u - 0.5) * 2.0 * 3.0 is monotone in u,
+    so a value that gives the recorded bits lies within a few units in the last place of vel_y / 6 + 0.5."""
+    vel_y = np.asarray(vel_y, np.float64)
+    u0 = np.where(np.asarray(vel_x) > 0, 0.75, 0.25)
+    u1 = np.zeros_like(vel_y)
+    found = np.zeros(vel_y.shape, bool)
+    lo = vel_y / 6.0 + 0.5
+    hi = lo.copy()
+    for k in range(17):
+        for cand in ((lo,) if k == 0 else (lo, hi)):
+            ok = ~found & (cand >= 0.0) & (cand < 1.0) & (bits64((cand - 0.5) * 2.0 * 3.0) == bits64(vel_y))
+            u1[ok] = cand[ok]
+            found |= ok
+        lo = np.nextafter(lo, -np.inf)
+        hi = np.nextafter(hi, np.inf)
+    return np.stack([u0, u1]), found
+
+
+def bits64(a):
+    return np.ascontiguousarray(a, np.float64).view(np.uint64)
+
+
+def replay(rec, set_state_raw, step, get_state_raw, get_obs=None, set_rng_draws=None):
     """Teacher-forced replay through an engine given as three callables.  Returns a dict of counts;
-    raises AssertionError where a bar is missed."""
+    raises AssertionError where a bar is missed.  With set_rng_draws (an engine that takes the values of Pong's ball
+    reset from its caller) the velocities a point leaves behind are checked too: the values are recovered from the
+    recorded post-step state and handed over before the step."""
     exact_reals = rec.real_is_f64  # Pong / Breakout game state: plain binary64 arithmetic, no libm
     report = {"steps": rec.steps, "real_elements": 0, "real_elements_differing": 0, "max_rel": 0.0, "unpinned_events": 0,
               "frames": 0}
     pre = rec.init
     for t in range(rec.steps):
         set_state_raw(pre)
-        rew, done = step(rec.actions[t])
-        got_r, got_i = rec.split(np.ascontiguousarray(get_state_raw()))
         want_r, want_i = rec.split(rec.images[t])
         pre_r, pre_i = rec.split(pre)
+        recovered = None
+        if rec.env_id == PONG and set_rng_draws is not None and (rec.rewards[t] != 0).any():
+            u, recovered = pong_draws_from(want_r[2], want_r[3])
+            set_rng_draws(u)  # envs that score no point on this step ignore theirs
+        rew, done = step(rec.actions[t])
+        got_r, got_i = rec.split(np.ascontiguousarray(get_state_raw()))
         assert np.array_equal(np.asarray(done, np.uint8), rec.dones[t]), "done differs at step %d" % t
         assert np.array_equal(got_i, want_i), "integer state differs at step %d" % t
         mask = np.ones((rec.n_real, rec.n), bool)  # components the reference's unseeded Random did not set
         if rec.env_id == PONG:
             scored = rec.rewards[t] != 0
+            if recovered is not None:
+                report["replayed_draws"] = report.get("replayed_draws", 0) + int((scored & recovered).sum())
+                scored = scored & ~recovered  # what is left is a velocity no value of NextDouble() gives
             mask[2:4, scored] = False
             assert np.isin(np.abs(want_r[2, scored]), [3.0]).all() and (np.abs(want_r[3, scored]) <= 3.0).all()
             report["unpinned_events"] += int(scored.sum())

@@ -1,0 +1,137 @@
+"""gx_vec_set_rng_draws: the two NextDouble() values of Pong's ResetBall() / Reset() (Envs.Pong.cs:58-59, 163-164)
+supplied by the caller, as a recording of the reference would supply them.  Checked against the formula of the source,
+against the oracle given the same values, and for what must not change: envs that reset no ball, later launches."""
+import numpy as np
+import pytest
+
+from gpu_common import L, bits, ctx, make_pair, random_actions
+from gym_amd.engine import DeviceBatch
+
+pytestmark = pytest.mark.gpu
+
+
+def _draws(rng, n):
+    u = rng.random((2, n))
+    # the comparison is `> 0.5`; the ends of [0, 1)
+    u[0, :6] = [0.5, np.nextafter(0.5, 1.0), 0.0, np.nextafter(1.0, 0.0), 0.25, 0.75]
+    u[1, :6] = [0.0, np.nextafter(1.0, 0.0), 0.5, 0.5, np.nextafter(0.5, 0.0), 1.0 / 3.0]
+    return u
+
+
+def _same(g, o):
+    gr, gi = g.get_state()
+    orr, oi = o.get_state()
+    return np.array_equal(bits(gr), bits(orr)) and np.array_equal(gi, oi)
+
+
+def test_reset_takes_the_supplied_draws(oracle):
+    n = 301
+    g, o = make_pair(oracle, L.ENV_PONG, n, seed=5)
+    u = _draws(np.random.default_rng(1), n)
+    g.set_rng_draws(u); o.set_rng_draws(u)
+    g.reset(); o.reset()
+    reals, ints = g.get_state()
+    # Envs.Pong.cs:56-59
+    assert np.all(reals[0] == 80.0) and np.all(reals[1] == 105.0)
+    assert np.array_equal(reals[2], np.where(u[0] > 0.5, 3.0, -3.0))
+    assert np.array_equal(bits(reals[3]), bits((u[1] - 0.5) * 2.0 * 3.0))
+    assert not ints.any()
+    assert _same(g, o) and np.array_equal(g.get_obs(), o.get_obs())
+    # the draws served that launch only: from here on both follow their generators again, in step
+    rng = np.random.default_rng(2)
+    for t in range(300):
+        a = random_actions(rng, L.ENV_PONG, n)
+        _, rew, done, _ = g.step_host(a)
+        orew, odone, _ = o.step(a)
+        assert np.array_equal(rew.astype(np.float64), orew) and np.array_equal(done, odone)
+    assert _same(g, o)
+
+
+def test_ball_reset_inside_step_takes_the_supplied_draws(oracle):
+    n = 256
+    g, o = make_pair(oracle, L.ENV_PONG, n, seed=6, flags=L.AUTORESET | L.RECORD_STATS)
+    plain = DeviceBatch(ctx(), L.ENV_PONG, n, seed=6, flags=L.AUTORESET | L.RECORD_STATS)
+    i = np.arange(n)
+    left, right = i % 4 == 0, i % 4 == 1        # the ball leaves on this step; the others play on
+    reals = np.zeros((6, n))
+    reals[0] = np.where(left, 1.0, np.where(right, 159.0, 40.0 + (i % 60)))   # ballX
+    reals[1] = 150.0                                                            # ballY, clear of both paddles
+    reals[2] = np.where(left, -3.0, 3.0)
+    reals[3] = ((i % 7) - 3) * 0.5
+    ints = np.zeros((3, n), np.int32)
+    ints[0] = i % 20; ints[1] = (3 * i) % 20; ints[2] = 10 + i
+    # one env wins the game on this point: the auto-reset that follows is a second ball reset of the same step
+    ints[1, 0] = 20
+    for b in (g, o, plain):
+        b.set_state(reals, ints)
+    u = _draws(np.random.default_rng(3), n)
+    g.set_rng_draws(u); o.set_rng_draws(u)
+    a = np.zeros(n, np.int32)
+    obs, rew, done, _ = g.step_host(a, want_obs=True)
+    orew, odone, _ = o.step(a)
+    plain.step_host(a)
+    assert np.array_equal(rew.astype(np.float64), orew) and np.array_equal(done, odone)
+    assert np.array_equal(rew != 0, left | right) and done[0] and done.sum() == 1
+    assert _same(g, o) and np.array_equal(obs, o.get_obs())
+    r2, i2 = g.get_state()
+    pr, pi = plain.get_state()
+    scored = (left | right) & (done == 0)
+    # Envs.Pong.cs:161-164 with the supplied values
+    assert np.all(r2[0, scored] == 80.0) and np.all(r2[1, scored] == 105.0)
+    assert np.array_equal(r2[2, scored], np.where(u[0] > 0.5, 3.0, -3.0)[scored])
+    assert np.array_equal(bits(r2[3, scored]), bits(((u[1] - 0.5) * 2.0 * 3.0)[scored]))
+    # env 0: the supplied values went to ResetBall(), the Reset() after it drew from the generator like the plain batch's
+    assert np.array_equal(bits(r2[:, 0]), bits(pr[:, 0])) and np.array_equal(i2[:, 0], pi[:, 0])
+    # envs that reset no ball are what they are without supplied draws, and nothing but the two velocities differs elsewhere
+    quiet = ~(left | right)
+    assert np.array_equal(bits(r2[:, quiet]), bits(pr[:, quiet])) and np.array_equal(i2, pi)
+    assert np.array_equal(bits(r2[[0, 1, 4, 5]]), bits(pr[[0, 1, 4, 5]]))
+    # the next launches use the generator again
+    rng = np.random.default_rng(4)
+    for t in range(200):
+        a = random_actions(rng, L.ENV_PONG, n)
+        _, rew, done, _ = g.step_host(a)
+        orew, odone, _ = o.step(a)
+        assert np.array_equal(rew.astype(np.float64), orew) and np.array_equal(done, odone)
+    assert _same(g, o)
+    assert g.stats().episodes == o.stats().episodes >= 1
+    plain.close()
+
+
+def test_rollout_and_withdrawal(oracle):
+    n = 130
+    u = _draws(np.random.default_rng(5), n)
+    # a fused rollout: the supplied values serve its first ball reset per env
+    g, o = make_pair(oracle, L.ENV_PONG, n, seed=7, flags=L.AUTORESET | L.RECORD_STATS)
+    g.reset(); o.reset()
+    g.set_rng_draws(u); o.set_rng_draws(u)
+    g.rollout(1, L.POLICY_RANDOM)
+    o.step_random()
+    assert _same(g, o)
+    # withdrawn draws leave no trace
+    a = DeviceBatch(ctx(), L.ENV_PONG, n, seed=9)
+    b = DeviceBatch(ctx(), L.ENV_PONG, n, seed=9)
+    a.set_rng_draws(u)
+    a.set_rng_draws(None)
+    a.reset(); b.reset()
+    assert np.array_equal(a.get_state_raw(), b.get_state_raw())
+    a.close(); b.close()
+
+
+def test_misuse_is_a_status(oracle):
+    n = 8
+    g = DeviceBatch(ctx(), L.ENV_PONG, n, seed=1)
+    for bad in (np.zeros(2 * n - 1), np.full((2, n), 1.0), np.full((2, n), -1e-9), np.full((2, n), np.nan)):
+        with pytest.raises(L.GymxError) as e:
+            g.set_rng_draws(bad)
+        assert e.value.code == L.GX_ERR_INVALID
+    c = DeviceBatch(ctx(), L.ENV_CARTPOLE, n, seed=1)
+    with pytest.raises(L.GymxError) as e:
+        c.set_rng_draws(np.zeros((2, n)))
+    assert e.value.code == L.GX_ERR_UNSUPPORTED
+    # the batch is as usable as before
+    h = DeviceBatch(ctx(), L.ENV_PONG, n, seed=1)
+    g.reset(); h.reset()
+    assert np.array_equal(g.get_state_raw(), h.get_state_raw())
+    for b in (g, c, h):
+        b.close()

@@ -31,6 +31,11 @@ def oracle_callables(oracle, rec):
     return v, v.set_state_raw, step, v.get_state_raw, v.get_obs
 
 
+def draws_setter(engine, rec):
+    """Pong's ball-reset values can be handed to the engine (gx_vec_set_rng_draws / the oracle's twin)"""
+    return engine.set_rng_draws if rec.env_id == RR.PONG else None
+
+
 def make_self_recording(oracle, name, nact, limit, n=96, steps=80):
     eid = getattr(oracle, name)
     src = oracle.OracleVec(eid, n, seed=77)
@@ -64,11 +69,15 @@ def test_format_round_trip_and_replay_rules(oracle, tmp_path, name, nact, limit)
            (rec.env_id, rec.n, rec.steps, rec.n_real, rec.real_is_f64, rec.n_int)
     assert np.array_equal(back.init, rec.init) and all(np.array_equal(a, b) for a, b in zip(back.images, rec.images))
     assert sorted(back.frames) == sorted(rec.frames)
-    _, set_state, step, get_state, get_obs = oracle_callables(oracle, back)
+    v, set_state, step, get_state, get_obs = oracle_callables(oracle, back)
     rep = RR.replay(back, set_state, step, get_state, get_obs)
     assert rep["real_elements_differing"] == 0
     if name in ("PONG", "BREAKOUT"):
         assert rep["unpinned_events"] > 0 and rep["frames"] == 4
+    if name == "PONG":  # with the ball-reset values handed over nothing is left out
+        full = RR.replay(back, set_state, step, get_state, get_obs, v.set_rng_draws)
+        assert full["unpinned_events"] == 0 and full["replayed_draws"] == rep["unpinned_events"]
+        assert full["real_elements_differing"] == 0 and full["real_elements"] > rep["real_elements"]
     # a corrupted reward or state must be caught
     back.rewards[5][3] += 1.0
     with pytest.raises(AssertionError):
@@ -92,16 +101,18 @@ def test_replay_rules_through_the_abi(oracle, name, nact, limit):
     def step(a):
         _, r, d, _ = g.step_host(a)
         return r, d
-    rep = RR.replay(rec, g.set_state_raw, step, g.get_state_raw, g.get_obs)
+    rep = RR.replay(rec, g.set_state_raw, step, g.get_state_raw, g.get_obs, draws_setter(g, rec))
     assert rep["real_elements_differing"] <= 2, rep
+    if name == "PONG":
+        assert rep["unpinned_events"] == 0 and rep["replayed_draws"] > 0, rep
 
 
 @pytest.mark.skipif(not RECORDED, reason=NEED)
 @pytest.mark.parametrize("path", RECORDED or [None], ids=[os.path.basename(p) for p in RECORDED] or ["none"])
 def test_oracle_reproduces_the_reference(oracle, path):
     rec = RR.read(path)
-    _, set_state, step, get_state, get_obs = oracle_callables(oracle, rec)
-    rep = RR.replay(rec, set_state, step, get_state, get_obs)
+    v, set_state, step, get_state, get_obs = oracle_callables(oracle, rec)
+    rep = RR.replay(rec, set_state, step, get_state, get_obs, draws_setter(v, rec))
     print(os.path.basename(path), rep)
 
 
@@ -119,5 +130,5 @@ def test_gpu_reproduces_the_reference(path):
     def step(a):
         _, r, d, _ = g.step_host(a)
         return r, d
-    rep = RR.replay(rec, g.set_state_raw, step, g.get_state_raw, g.get_obs)
+    rep = RR.replay(rec, g.set_state_raw, step, g.get_state_raw, g.get_obs, draws_setter(g, rec))
     print(os.path.basename(path), rep)
