@@ -136,8 +136,9 @@ public sealed unsafe class GpuVectorEnv<TState, TAction, TObs> : IDisposable
         _imageFresh = false;
     }
 
-    /// <summary>Pong: the two <c>_random.NextDouble()</c> values of each env's next ball reset (Envs.Pong.cs:163-164),
-    /// <c>u[2][NumEnvs]</c>, for the next Reset / Step only.  An empty span withdraws draws not used yet.</summary>
+    /// <summary>The <c>_random.NextDouble()</c> values of each env's next draw inside Step, for the next Reset / Step only:
+    /// Pong <c>u[2][NumEnvs]</c> (ball reset, Envs.Pong.cs:163-164), Breakout <c>u[1][NumEnvs]</c> (release of the ball,
+    /// Envs.Breakout.cs:100).  An empty span withdraws values not used yet.</summary>
     public void SetRngDraws(ReadOnlySpan<double> u)
     {
         fixed (double* p = u) Native.Check(Native.gx_vec_set_rng_draws(_vec.DangerousGetHandle(), u.IsEmpty ? null : p, (nuint)u.Length));

@@ -83,7 +83,7 @@ struct gx_vec {
   uint8_t* d_frames = nullptr;
   uint32_t* d_render = nullptr;  // frame envs: one packed record per env between the step and the raster
   uint32_t* d_table = nullptr;
-  double* d_forced = nullptr;   // Pong: [2][stride] caller-supplied uniforms (gx_vec_set_rng_draws), allocated on first use
+  double* d_forced = nullptr;   // Pong [2][stride], Breakout [1][stride]: caller-supplied uniforms (gx_vec_set_rng_draws), allocated on first use
   bool forced_pending = false;  // the next step or reset launch hands d_forced to its kernel, once
   uint32_t* d_error = nullptr;
   void* d_actions = nullptr;  // staging for the host path
@@ -866,14 +866,15 @@ extern "C" int gx_vec_set_state(gx_vec* v, const void* host, size_t bytes) {
 
 extern "C" int gx_vec_set_rng_draws(gx_vec* v, const double* u, size_t count) {
   if (!v) return fail(GX_ERR_INVALID, "gx_vec_set_rng_draws: null batch");
-  if (v->desc.env_id != GX_ENV_PONG)
-    return fail(GX_ERR_UNSUPPORTED, "gx_vec_set_rng_draws: env id %d; only Pong draws inside Step (its ball reset) -- replay the other envs with gx_vec_set_state", v->desc.env_id);
+  if (v->desc.env_id != GX_ENV_PONG && v->desc.env_id != GX_ENV_BREAKOUT)
+    return fail(GX_ERR_UNSUPPORTED, "gx_vec_set_rng_draws: env id %d; Pong (ball reset) and Breakout (ball release) take their draws from the caller -- replay the other envs with gx_vec_set_state", v->desc.env_id);
+  const size_t per_env = v->desc.env_id == GX_ENV_PONG ? 2 : 1;
   if (!u || count == 0) {  // withdraw draws that were set and not used yet
     v->forced_pending = false;
     return GX_OK;
   }
-  if (count != 2 * (size_t)v->n)
-    return fail(GX_ERR_INVALID, "gx_vec_set_rng_draws: %zu values, expected 2 x %llu ([2][num_envs])", count, (unsigned long long)v->n);
+  if (count != per_env * (size_t)v->n)
+    return fail(GX_ERR_INVALID, "gx_vec_set_rng_draws: %zu values, expected %zu x %llu ([%zu][num_envs])", count, per_env, (unsigned long long)v->n, per_env);
   for (size_t i = 0; i < count; i++)
     if (!(u[i] >= 0.0 && u[i] < 1.0))  // Random.NextDouble() is in [0, 1); NaN fails the test too
       return fail(GX_ERR_INVALID, "gx_vec_set_rng_draws: value %zu is %g, outside [0, 1)", i, u[i]);
@@ -888,7 +889,7 @@ extern "C" int gx_vec_set_rng_draws(gx_vec* v, const double* u, size_t count) {
   }
   HIP_TRY(hipStreamSynchronize(c->compute));  // a launch that still reads the previous draws
   if (v->last_stream && v->last_stream != c->compute) HIP_TRY(hipStreamSynchronize(v->last_stream));
-  int rc = copy_rows(v->d_forced, u, sizeof(double), 2, v->n, v->stride, v->n, hipMemcpyHostToDevice, c->copy);
+  int rc = copy_rows(v->d_forced, u, sizeof(double), (int)per_env, v->n, v->stride, v->n, hipMemcpyHostToDevice, c->copy);
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(c->copy));
   v->forced_pending = true;

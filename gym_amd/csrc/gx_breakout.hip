@@ -33,6 +33,9 @@ struct State {
   int32_t score, lives, steps;
   bool stuck;
   uint32_t bricks[4];
+  // the NextDouble() value the caller supplied for this env's next release of the ball (gx_vec_set_rng_draws);
+  // negative: none, the generator is used
+  double force0 = -1.0;
 };
 
 __device__ __forceinline__ double dmax(double a, double b) { return a >= b ? a : b; }
@@ -60,8 +63,15 @@ __device__ __forceinline__ void step(State& s, int action, const RngKey& key, ui
   if (action == 1) {
     if (s.stuck) {
       s.stuck = false;
-      // the env's only random draw: in-step stream, draw 0
-      s.ballVelX = (philox_block(key, env, 1, 0).uniform(0) - 0.5) * 2.0 * kBallSpeed;
+      // the env's only random draw: in-step stream, draw 0, unless the caller supplied the value
+      double u;
+      if (s.force0 >= 0.0) {
+        u = s.force0;
+        s.force0 = -1.0;
+      } else {
+        u = philox_block(key, env, 1, 0).uniform(0);
+      }
+      s.ballVelX = (u - 0.5) * 2.0 * kBallSpeed;
       s.ballVelY = -kBallSpeed;
     }
   } else if (action == 2) {
@@ -154,7 +164,9 @@ struct BreakoutGame {
   using State = bk::State;
   static constexpr int kActions = 4;  // Discrete(4), Envs.Breakout.cs:44
   static __device__ __forceinline__ void load(const StepArgs& a, uint64_t i, State& s) { bk::load(a, i, s); }
-  static __device__ __forceinline__ void prime(const StepArgs&, uint64_t, State&) {}
+  static __device__ __forceinline__ void prime(const StepArgs& a, uint64_t i, State& s) {
+    if (a.forced_draws) s.force0 = a.forced_draws[i];
+  }
   static __device__ __forceinline__ void store(const StepArgs& a, uint64_t i, const State& s) { bk::store(a, i, s); }
   static __device__ __forceinline__ void reset(State& s, const RngKey&, uint64_t) { bk::reset(s); }
   static __device__ __forceinline__ void step(State& s, int action, const RngKey& key, uint64_t env, float& reward, bool& done) {

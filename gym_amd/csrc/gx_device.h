@@ -285,8 +285,8 @@ struct StepArgs {
   void* out_reward;        // [k_steps][stride] float or double
   uint8_t* out_done;       // [k_steps][stride]
   uint8_t* out_truncated;  // [k_steps][stride] or nullptr
-  // Pong, one launch only (gx_vec_set_rng_draws): [2][stride] uniforms that stand in for the generator in each
-  // env's next ball reset; nullptr otherwise
+  // one launch only (gx_vec_set_rng_draws): uniforms that stand in for the generator in each env's next ball
+  // reset (Pong, [2][stride]) or release of the ball (Breakout, [1][stride]); nullptr otherwise
   const double* forced_draws;
   uint64_t num_envs;
   uint64_t stride;

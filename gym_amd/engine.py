@@ -96,8 +96,9 @@ class DeviceBatch:
         L.check(L.load().gx_vec_set_state(self._h, _ptr(buf), buf.size))
 
     def set_rng_draws(self, u):
-        """Pong: the two NextDouble() values each env's next ball reset takes (Envs.Pong.cs:163-164), u[2][num_envs]
-        in [0, 1), for the next reset / step / rollout launch only; None withdraws draws not used yet"""
+        """The NextDouble() values of each env's next in-Step draw, in [0, 1), for the next reset / step / rollout launch
+        only: Pong u[2][num_envs] (ball reset, Envs.Pong.cs:163-164), Breakout u[1][num_envs] (release of the ball,
+        Envs.Breakout.cs:100); None withdraws values not used yet"""
         if u is None:
             L.check(L.load().gx_vec_set_rng_draws(self._h, None, 0))
             return

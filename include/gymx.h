@@ -210,15 +210,16 @@ int gx_vec_reset(gx_vec* vec);
  *                  (fired every 60 steps at most, gone within 40), the image holds two. */
 int gx_vec_get_state(gx_vec* vec, void* host_soa, size_t bytes);
 int gx_vec_set_state(gx_vec* vec, const void* host_soa, size_t bytes);
-/* Pong's ResetBall(), Envs.Pong.cs:159-165, and the same two lines of Reset(), :58-59: the two
- * _random.NextDouble() values each env's next ball reset consumes, supplied by the caller (a recording of the
- * reference) instead of drawn from the engine's generator.  u is host double[2][num_envs]: u[i] decides the
- * horizontal direction (> 0.5: towards the agent's paddle), u[num_envs + i] the vertical speed; every value in
- * [0, 1) (else GX_ERR_INVALID), count = 2 * num_envs.  They serve the next launch only -- gx_vec_reset, or the next
- * step or rollout, in which the first ball reset of env i (at most one per step: a point scored) takes them and
- * any later one draws from the generator again; envs that reset no ball in that launch ignore them.  u = NULL or
- * count = 0 withdraws draws not used yet.  Pong only: GX_ERR_UNSUPPORTED for the other envs, whose recorded
- * runs are replayed by writing the recorded states with gx_vec_set_state.  Synchronous. */
+/* The draws the reference's unseeded Random makes inside Step(), supplied by the caller (a recording of the
+ * reference) instead of drawn from the engine's generator.  u is host double[k][num_envs], every value in [0, 1)
+ * as _random.NextDouble() gives them (else GX_ERR_INVALID), count = k * num_envs:
+ *   Pong, k = 2      ResetBall(), Envs.Pong.cs:159-165, and the same two lines of Reset(), :58-59: u[i] decides the
+ *                    horizontal direction (> 0.5: towards the agent's paddle), u[num_envs + i] the vertical speed;
+ *   Breakout, k = 1  the horizontal speed when FIRE releases the ball, Envs.Breakout.cs:100.
+ * They serve the next launch only -- gx_vec_reset, or the next step or rollout, in which env i's first such event
+ * (at most one per step) takes them and any later one draws from the generator again; envs without the event in
+ * that launch ignore them.  u = NULL or count = 0 withdraws values not used yet.  GX_ERR_UNSUPPORTED for the other
+ * envs, whose recorded runs are replayed by writing the recorded states with gx_vec_set_state.  Synchronous. */
 int gx_vec_set_rng_draws(gx_vec* vec, const double* u, size_t count);
 /* Observation of every env as Reset()/Step() would return it: classic control
  * float[obs_dim][num_envs] (double under GX_MODE_FP64); tabular int32[num_envs]; Pong, Breakout and SpaceInvaders uint8[num_envs][100800].

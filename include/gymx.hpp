@@ -186,7 +186,8 @@ class Batch {
     return s;
   }
   void SetState(const std::vector<uint8_t>& s) { check(gx_vec_set_state(h_, s.data(), s.size())); }
-  // Pong: u[2][NumEnvs] stands in for the two NextDouble() of each env's next ball reset (Envs.Pong.cs:163-164)
+  // Pong u[2][NumEnvs]: the two NextDouble() of each env's next ball reset (Envs.Pong.cs:163-164); Breakout
+  // u[1][NumEnvs]: the one of its next release of the ball (Envs.Breakout.cs:100)
   void SetRngDraws(const std::vector<double>& u) { check(gx_vec_set_rng_draws(h_, u.empty() ? nullptr : u.data(), u.size())); }
   // zero-copy path
   gx_view View() { gx_view v{}; check(gx_vec_device_view(h_, &v)); return v; }

@@ -1290,6 +1290,9 @@ typedef struct {
   int32_t score, lives, ballStuck;
   uint8_t bricks[BK_BRICK_ROWS][BK_BRICK_COLS];
   int32_t steps;
+  /* recorded NextDouble() value for the next release of the ball (gxo_vec_set_rng_draws); used once */
+  int forced;
+  double force0;
 } breakout_t;
 
 /* Envs.Breakout.cs:62-87 (no random draw) */
@@ -1320,7 +1323,9 @@ static int breakout_step(env_obj* e, const void* action, const rng_ctx* r, doubl
       if (c->ballStuck) {
         c->ballStuck = 0;
         /* the only random draw of the env: stream 1 (inside Step), draw 0 */
-        c->ballVelX = (gxo_rng_uniform(r->seed, r->env_index, r->tick, 1, 0) - 0.5) * 2.0 * BK_BALL_SPEED;
+        double u = c->forced ? c->force0 : gxo_rng_uniform(r->seed, r->env_index, r->tick, 1, 0);
+        c->forced = 0;
+        c->ballVelX = (u - 0.5) * 2.0 * BK_BALL_SPEED;
         c->ballVelY = -BK_BALL_SPEED;
       }
       break;
@@ -1892,20 +1897,29 @@ static void wrapped_reset(gxo_vec* v, uint64_t i, const rng_ctx* r) {
 /* Recorded draws serve one pass over the batch (one Reset or one Step of every env): what a pass did not use
  * is dropped. */
 static void pong_drop_draws(gxo_vec* v) {
-  if (v->env_id != GXO_PONG) return;
-  for (uint64_t i = 0; i < v->n; i++) ((pong_t*)v->envs[i])->forced = 0;
+  for (uint64_t i = 0; i < v->n; i++) {
+    if (v->env_id == GXO_PONG) ((pong_t*)v->envs[i])->forced = 0;
+    if (v->env_id == GXO_BREAKOUT) ((breakout_t*)v->envs[i])->forced = 0;
+  }
 }
 
-/* u[2][N]: the two _random.NextDouble() values of env i's next ball reset (Envs.Pong.cs:58-59, 163-164), in place
- * of the restatement's generator, for the next gxo_vec_reset or step only.  Returns -1 for another env. */
+/* The _random.NextDouble() values of env i's next in-Step draw, in place of the restatement's generator, for the
+ * next gxo_vec_reset or step only: Pong u[2][N], the ball reset (Envs.Pong.cs:58-59, 163-164); Breakout u[1][N],
+ * the release of the ball (Envs.Breakout.cs:100).  Returns -1 for another env. */
 int gxo_vec_set_rng_draws(gxo_vec* v, const double* u) {
-  if (v->env_id != GXO_PONG) return -1;
+  if (v->env_id != GXO_PONG && v->env_id != GXO_BREAKOUT) return -1;
   for (uint64_t i = 0; i < v->n; i++) {
-    pong_t* c = (pong_t*)v->envs[i];
-    c->forced = u != NULL;
-    if (u) {
-      c->force0 = u[i];
-      c->force1 = u[v->n + i];
+    if (v->env_id == GXO_PONG) {
+      pong_t* c = (pong_t*)v->envs[i];
+      c->forced = u != NULL;
+      if (u) {
+        c->force0 = u[i];
+        c->force1 = u[v->n + i];
+      }
+    } else {
+      breakout_t* c = (breakout_t*)v->envs[i];
+      c->forced = u != NULL;
+      if (u) c->force0 = u[i];
     }
   }
   return 0;

@@ -107,8 +107,9 @@ int gxo_vec_step_random(gxo_vec* v, void* actions_out, double* reward, uint8_t* 
  * n_int arrays of int32 of length N.  Same layout as gx_vec_get_state. */
 void gxo_vec_get_state(const gxo_vec* v, void* buf);
 void gxo_vec_set_state(gxo_vec* v, const void* buf);
-/* Pong: u[2][N] replaces the generator in each env's next ball reset (Envs.Pong.cs:58-59, 163-164) during the
- * next reset or step of the batch; NULL withdraws.  -1 for another env. */
+/* Pong: u[2][N] replaces the generator in each env's next ball reset (Envs.Pong.cs:58-59, 163-164), Breakout:
+ * u[1][N] in its next release of the ball (Envs.Breakout.cs:100), during the next reset or step of the batch;
+ * NULL withdraws.  -1 for another env. */
 int gxo_vec_set_rng_draws(gxo_vec* v, const double* u);
 /* Observation: classic control float[obs_dim][N]; tabular/Dummy int32[N];
  * Pong uint8[N][100800]. */

@@ -167,12 +167,13 @@ class OracleVec:
         lib().gxo_vec_set_state(self._h, _ptr(buf))
 
     def set_rng_draws(self, u):
-        """Pong: u[2][N] stands in for the generator in each env's next ball reset, for the next reset / step only"""
+        """Pong u[2][N] (ball reset), Breakout u[1][N] (release of the ball): stands in for the generator in each env's
+        next such event, for the next reset / step only"""
         if u is None:
             assert lib().gxo_vec_set_rng_draws(self._h, None) == 0
             return
         u = np.ascontiguousarray(u, dtype=np.float64)
-        assert u.size == 2 * self.n
+        assert u.size == (2 if self.env_id == PONG else 1) * self.n
         assert lib().gxo_vec_set_rng_draws(self._h, _ptr(u)) == 0
 
     def split_state(self, buf):

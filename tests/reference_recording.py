@@ -103,24 +103,30 @@ def record_from(engine_step, get_state_raw, get_obs, env_id, n, n_real, real_is_
     return rec
 
 
-def pong_draws_from(vel_x, vel_y):
-    """Values of `_random.NextDouble()` that Envs.Pong.cs:163-164 turns into a recorded ball velocity: (u[2][n], found[n]).
-    The direction needs any value on the right side of 0.5; the vertical speed (u - 0.5) * 2.0 * 3.0 is monotone in u,
-    so a value that gives the recorded bits lies within a few units in the last place of vel_y / 6 + 0.5."""
-    vel_y = np.asarray(vel_y, np.float64)
-    u0 = np.where(np.asarray(vel_x) > 0, 0.75, 0.25)
-    u1 = np.zeros_like(vel_y)
-    found = np.zeros(vel_y.shape, bool)
-    lo = vel_y / 6.0 + 0.5
+def draw_for_speed(vel):
+    """A value u of `_random.NextDouble()` with (u - 0.5) * 2.0 * 3.0 == vel bit for bit (Envs.Pong.cs:164,
+    Envs.Breakout.cs:100; both ball speeds are 3): (u[n], found[n]).  The expression is monotone in u, so such a value
+    lies within a few units in the last place of vel / 6 + 0.5."""
+    vel = np.asarray(vel, np.float64)
+    u = np.zeros_like(vel)
+    found = np.zeros(vel.shape, bool)
+    lo = vel / 6.0 + 0.5
     hi = lo.copy()
     for k in range(17):
         for cand in ((lo,) if k == 0 else (lo, hi)):
-            ok = ~found & (cand >= 0.0) & (cand < 1.0) & (bits64((cand - 0.5) * 2.0 * 3.0) == bits64(vel_y))
-            u1[ok] = cand[ok]
+            ok = ~found & (cand >= 0.0) & (cand < 1.0) & (bits64((cand - 0.5) * 2.0 * 3.0) == bits64(vel))
+            u[ok] = cand[ok]
             found |= ok
         lo = np.nextafter(lo, -np.inf)
         hi = np.nextafter(hi, np.inf)
-    return np.stack([u0, u1]), found
+    return u, found
+
+
+def pong_draws_from(vel_x, vel_y):
+    """Values of `_random.NextDouble()` that Envs.Pong.cs:163-164 turns into a recorded ball velocity: (u[2][n], found[n]).
+    The direction needs any value on the right side of 0.5."""
+    u1, found = draw_for_speed(vel_y)
+    return np.stack([np.where(np.asarray(vel_x) > 0, 0.75, 0.25), u1]), found
 
 
 def bits64(a):
@@ -130,8 +136,8 @@ def bits64(a):
 def replay(rec, set_state_raw, step, get_state_raw, get_obs=None, set_rng_draws=None):
     """Teacher-forced replay through an engine given as three callables.  Returns a dict of counts;
     raises AssertionError where a bar is missed.  With set_rng_draws (an engine that takes the values of Pong's ball
-    reset from its caller) the velocities a point leaves behind are checked too: the values are recovered from the
-    recorded post-step state and handed over before the step."""
+    reset and Breakout's release of the ball from its caller) what those draws set is checked too: the values are
+    recovered from the recorded post-step state and handed over before the step."""
     exact_reals = rec.real_is_f64  # Pong / Breakout game state: plain binary64 arithmetic, no libm
     report = {"steps": rec.steps, "real_elements": 0, "real_elements_differing": 0, "max_rel": 0.0, "unpinned_events": 0,
               "frames": 0}
@@ -144,6 +150,10 @@ def replay(rec, set_state_raw, step, get_state_raw, get_obs=None, set_rng_draws=
         if rec.env_id == PONG and set_rng_draws is not None and (rec.rewards[t] != 0).any():
             u, recovered = pong_draws_from(want_r[2], want_r[3])
             set_rng_draws(u)  # envs that score no point on this step ignore theirs
+        if rec.env_id == BREAKOUT and set_rng_draws is not None and ((rec.actions[t] == 1) & (pre_i[2] == 1)).any():
+            # the release leaves ballVelX as drawn (the stuck ball sits over the paddle, three pixels cannot reach a wall)
+            u, recovered = draw_for_speed(want_r[2])
+            set_rng_draws(u)
         rew, done = step(rec.actions[t])
         got_r, got_i = rec.split(np.ascontiguousarray(get_state_raw()))
         assert np.array_equal(np.asarray(done, np.uint8), rec.dones[t]), "done differs at step %d" % t
@@ -159,6 +169,9 @@ def replay(rec, set_state_raw, step, get_state_raw, get_obs=None, set_rng_draws=
             report["unpinned_events"] += int(scored.sum())
         if rec.env_id == BREAKOUT:
             fired = (rec.actions[t] == 1) & (pre_i[2] == 1)
+            if recovered is not None:
+                report["replayed_draws"] = report.get("replayed_draws", 0) + int((fired & recovered).sum())
+                fired = fired & ~recovered
             mask[0, fired] = False
             mask[2, fired] = False
             assert (np.abs(want_r[2, fired]) <= 3.0).all()

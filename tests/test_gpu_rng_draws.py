@@ -1,5 +1,6 @@
-"""gx_vec_set_rng_draws: the two NextDouble() values of Pong's ResetBall() / Reset() (Envs.Pong.cs:58-59, 163-164)
-supplied by the caller, as a recording of the reference would supply them.  Checked against the formula of the source,
+"""gx_vec_set_rng_draws: the two NextDouble() values of Pong's ResetBall() / Reset() (Envs.Pong.cs:58-59, 163-164) and
+the one of Breakout's release of the ball (Envs.Breakout.cs:100) supplied by the caller, as a recording of the
+reference would supply them.  Checked against the formula of the source,
 against the oracle given the same values, and for what must not change: envs that reset no ball, later launches."""
 import numpy as np
 import pytest
@@ -118,6 +119,44 @@ def test_rollout_and_withdrawal(oracle):
     a.close(); b.close()
 
 
+def test_breakout_release_takes_the_supplied_draw(oracle):
+    n = 200
+    g, o = make_pair(oracle, L.ENV_BREAKOUT, n, seed=3)
+    plain = DeviceBatch(ctx(), L.ENV_BREAKOUT, n, seed=3)
+    for b in (g, o, plain):
+        b.reset()
+    rng = np.random.default_rng(6)
+    # a few steps of paddle movement with the ball still on the paddle, so that it is released from different places
+    for t in range(5):
+        a = rng.integers(2, 4, n).astype(np.int32)
+        g.step_host(a); o.step(a); plain.step_host(a)
+    u = rng.random((1, n))
+    u[0, :4] = [0.0, 0.5, np.nextafter(1.0, 0.0), np.nextafter(0.5, 0.0)]
+    g.set_rng_draws(u); o.set_rng_draws(u)
+    a = np.where(np.arange(n) % 3 == 0, 0, 1).astype(np.int32)   # two in three press FIRE
+    pre_r, _ = g.get_state()
+    obs, rew, done, _ = g.step_host(a, want_obs=True)
+    orew, odone, _ = o.step(a)
+    plain.step_host(a)
+    assert np.array_equal(rew.astype(np.float64), orew) and np.array_equal(done, odone)
+    assert _same(g, o) and np.array_equal(obs, o.get_obs())
+    r2, i2 = g.get_state()
+    pr, pi = plain.get_state()
+    fired = a == 1
+    vx = (u[0] - 0.5) * 2.0 * 3.0   # Envs.Breakout.cs:100
+    assert np.array_equal(bits(r2[2, fired]), bits(vx[fired])) and np.all(r2[3, fired] == -3.0)
+    assert np.array_equal(bits(r2[0, fired]), bits((pre_r[0] + vx)[fired]))
+    assert np.array_equal(bits(r2[:, ~fired]), bits(pr[:, ~fired])) and np.array_equal(i2, pi)
+    # the value served that step only: a life lost and the next FIRE draw from the generator, in step with the oracle
+    for t in range(400):
+        a = rng.integers(0, 4, n).astype(np.int32)
+        _, rew, done, _ = g.step_host(a)
+        orew, odone, _ = o.step(a)
+        assert np.array_equal(rew.astype(np.float64), orew) and np.array_equal(done, odone)
+    assert _same(g, o)
+    plain.close()
+
+
 def test_misuse_is_a_status(oracle):
     n = 8
     g = DeviceBatch(ctx(), L.ENV_PONG, n, seed=1)
@@ -125,6 +164,11 @@ def test_misuse_is_a_status(oracle):
         with pytest.raises(L.GymxError) as e:
             g.set_rng_draws(bad)
         assert e.value.code == L.GX_ERR_INVALID
+    k = DeviceBatch(ctx(), L.ENV_BREAKOUT, n, seed=1)
+    with pytest.raises(L.GymxError) as e:
+        k.set_rng_draws(np.zeros((2, n)))   # Breakout draws one value per env
+    assert e.value.code == L.GX_ERR_INVALID
+    k.close()
     c = DeviceBatch(ctx(), L.ENV_CARTPOLE, n, seed=1)
     with pytest.raises(L.GymxError) as e:
         c.set_rng_draws(np.zeros((2, n)))

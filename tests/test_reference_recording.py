@@ -32,8 +32,9 @@ def oracle_callables(oracle, rec):
 
 
 def draws_setter(engine, rec):
-    """Pong's ball-reset values can be handed to the engine (gx_vec_set_rng_draws / the oracle's twin)"""
-    return engine.set_rng_draws if rec.env_id == RR.PONG else None
+    """Pong's ball-reset values and Breakout's release value can be handed to the engine (gx_vec_set_rng_draws / the
+    oracle's twin)"""
+    return engine.set_rng_draws if rec.env_id in (RR.PONG, RR.BREAKOUT) else None
 
 
 def make_self_recording(oracle, name, nact, limit, n=96, steps=80):
@@ -74,7 +75,7 @@ def test_format_round_trip_and_replay_rules(oracle, tmp_path, name, nact, limit)
     assert rep["real_elements_differing"] == 0
     if name in ("PONG", "BREAKOUT"):
         assert rep["unpinned_events"] > 0 and rep["frames"] == 4
-    if name == "PONG":  # with the ball-reset values handed over nothing is left out
+    if name in ("PONG", "BREAKOUT"):  # with the drawn values handed over nothing is left out
         full = RR.replay(back, set_state, step, get_state, get_obs, v.set_rng_draws)
         assert full["unpinned_events"] == 0 and full["replayed_draws"] == rep["unpinned_events"]
         assert full["real_elements_differing"] == 0 and full["real_elements"] > rep["real_elements"]
@@ -103,7 +104,7 @@ def test_replay_rules_through_the_abi(oracle, name, nact, limit):
         return r, d
     rep = RR.replay(rec, g.set_state_raw, step, g.get_state_raw, g.get_obs, draws_setter(g, rec))
     assert rep["real_elements_differing"] <= 2, rep
-    if name == "PONG":
+    if name in ("PONG", "BREAKOUT"):
         assert rep["unpinned_events"] == 0 and rep["replayed_draws"] > 0, rep
 
 
