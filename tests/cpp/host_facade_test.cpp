@@ -221,6 +221,35 @@ static void fp64_mode() {
   std::printf("Batch(MountainCar, FP64) x 257, 50 steps: max abs difference %.3g\n", worst);
 }
 
+// Replaying what the reference drew: Pong's Reset() with the two NextDouble() values handed over
+// (Envs.Pong.cs:56-59), against the source's formula and against the oracle given the same values.
+static void supplied_draws() {
+  const uint64_t n = 5;
+  BatchOptions o;
+  o.seed = 3;
+  Batch b(GX_ENV_PONG, n, o);
+  gxo_vec* ref = gxo_vec_create(GXO_PONG, n, 3, 0, 0, nullptr, 0);
+  const std::vector<double> u = {0.5, 0.75, 0.0, 0.999, 0.25, /* vertical */ 0.0, 0.5, 0.125, 0.875, 1.0 / 3.0};
+  b.SetRngDraws(u);
+  CHECK(gxo_vec_set_rng_draws(ref, u.data()) == 0);
+  b.Reset();
+  gxo_vec_reset(ref);
+  std::vector<uint8_t> got = b.GetState(), want(got.size());
+  gxo_vec_get_state(ref, want.data());
+  CHECK(got == want);
+  const double* r = reinterpret_cast<const double*>(got.data());
+  for (uint64_t i = 0; i < n; i++) {
+    CHECK(r[0 * n + i] == 80.0 && r[1 * n + i] == 105.0);
+    CHECK(r[2 * n + i] == (u[i] > 0.5 ? 3.0 : -3.0));
+    CHECK(r[3 * n + i] == (u[n + i] - 0.5) * 2.0 * 3.0);
+  }
+  gxo_vec_destroy(ref);
+  bool threw = false;
+  try { b.SetRngDraws(std::vector<double>(2 * n, 1.0)); } catch (const std::invalid_argument&) { threw = true; }
+  CHECK(threw);  // NextDouble() never returns 1
+  std::printf("Batch(Pong) x 5: Reset() with supplied draws equals the source's formula and the oracle\n");
+}
+
 int main() {
   int count = 0;
   if (gx_device_count(&count) != GX_OK || count == 0) {
@@ -234,6 +263,7 @@ int main() {
   vector_env_against_oracle();
   wrappers();
   fp64_mode();
+  supplied_draws();
   std::printf(failures ? "FAILED (%d)\n" : "ALL OK\n", failures);
   return failures ? 1 : 0;
 }
