@@ -19,8 +19,10 @@
 //             frame of env 0 (100800 bytes) when frame_every > 0 and (t + 1) % frame_every == 0 }
 //   image = n_real rows of num_envs reals (float32, or float64 when real_is_f64), then n_int rows of int32.
 // Draws of the reference's unseeded System.Random cannot be reproduced by another engine; the
-// harness therefore starts every step from the recorded pre-step state and knows which components
-// a draw inside Step may have set (Pong's ball velocity after a point, Breakout's after FIRE).
+// harness therefore starts every step from the recorded pre-step state.  What a draw inside Step
+// sets (Pong's ball velocity after a point, Breakout's after FIRE) it replays as well: it recovers
+// values of NextDouble() that give the recorded velocity bit for bit and hands them to the engine
+// (gx_vec_set_rng_draws) before the step, so the draws themselves need not be recorded.
 using System;
 using System.Collections.Generic;
 using System.IO;
