@@ -61,3 +61,26 @@ def test_rccl_path_with_one_rank():
     region, max-over-ranks of the time -- with a world of one"""
     j = _run("--force-dist", "--num-envs", "262144", "--no-extra", "--no-cpu-baseline")
     assert j["n_gpus"] == 1 and j["value"] > 0
+
+
+@pytest.mark.gpu
+def test_launched_by_torch_distributed_run_with_two_ranks():
+    """the launch line a multi-GPU run uses (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`): ranks come from the environment, bench.py starts
+    none of its own, rank 0 prints the one line.  Both ranks share the test box's GPU, collectives over gloo."""
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "5", "--warmup", "1", "--share-device", "--dist-backend", "gloo",
+                        "--num-envs", "262144", "--no-extra"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak"
+    assert abs(j["value"] - 2 * 262144 * 5 / (j["ms_per_step"] * 5e-3)) / j["value"] < 1e-6
