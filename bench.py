@@ -132,8 +132,8 @@ FRAME_ENVS = ("pong", "breakout", "spaceinvaders")
 ACROBOT_RK4_FLOPS = 196
 # the same per env-step as the hardware counts it, sin/cos polynomials and reciprocals included:
 # (SQ_INSTS_VALU_ADD_F64 + MUL_F64 + TRANS_F64 + 2 FMA_F64) x 64 lanes / (envs x K) of the fused
-# 64-step rollout, profiles/r1/fp64_valu_acrobot_rk4_rollout64.json
-ACROBOT_RK4_FLOPS_COUNTED = 525.1
+# 64-step rollout, profiles/r2/fp64_valu_acrobot_rk4_rollout64.json (tools/fp64_profile.sh)
+ACROBOT_RK4_FLOPS_COUNTED = 535.1
 
 
 def time_steps(batch, step_fn, steps, warmup, dist):
@@ -400,7 +400,7 @@ def main():
                            "frac": tf / FP64_VALU_PEAK_TFLOPS, "traffic": None, "kernel_ms": kernel_ms,
                            "fp64_flops_per_env_step": ACROBOT_RK4_FLOPS_COUNTED,
                            "arithmetic_only_flops_per_env_step": ACROBOT_RK4_FLOPS,
-                           "source": "SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64, profiles/r1/fp64_valu_acrobot_rk4_rollout64.json"}
+                           "source": "SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64, profiles/r2/fp64_valu_acrobot_rk4_rollout64.json"}
     # HBM bytes per launch from the rocprofv3 counter passes (FETCH_SIZE doubled as gfx950
     # needs, WRITE_SIZE as read) of this same command, taken by tools/collect_profiles.sh and
     # committed under profiles/; counters cannot be read from inside this process.
