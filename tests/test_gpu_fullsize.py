@@ -81,6 +81,43 @@ def test_tabular_64mi_window(oracle):
     g.close()
 
 
+def test_taxi_full_and_blackjack_64mi_device_actions(oracle):
+    """64 Mi envs of upstream Taxi-v3 and Blackjack stepped through the zero-copy path (actions in a device row: the
+    kernel form whose table is staged in 16-byte pieces): two windows of the batch against oracle batches keyed at the
+    same global env indices and fed the same actions, and the unsplit batch's range invariants"""
+    import torch
+    n = 1 << 26
+    for env_id, flags, k in ((L.ENV_TAXI, FUSED | L.TAXI_FULL, 24), (L.ENV_BLACKJACK, FUSED | L.BLACKJACK_FULL, 12)):
+        g = DeviceBatch(ctx(), env_id, n, seed=21, flags=flags)
+        g.reset()
+        windows = [(0, 2048), (n - 4099, 4096)]
+        os_ = [oracle.OracleVec(env_id, w, seed=21, flags=flags & ~L.RECORD_STATS, env_index_base=b) for b, w in windows]
+        for o in os_:
+            o.reset()
+        stride = int(g.view().stride)
+        dev = torch.zeros(stride, dtype=torch.int32, device="cuda")
+        stream = torch.cuda.Stream()
+        for t in range(k):
+            g.sample_actions(g.tick, dev.data_ptr(), stream.cuda_stream)
+            g.step_device(dev.data_ptr(), stream.cuda_stream)
+            stream.synchronize()
+            for (b, w), o in zip(windows, os_):
+                o.step(dev[b:b + w].cpu().numpy())
+        g.ctx.synchronize()
+        v = torch_views(g)
+        for (b, w), o in zip(windows, os_):
+            _, oi = o.get_state()
+            assert np.array_equal(v["state_int"][:, b:b + w].cpu().numpy(), oi)
+        st = v["state_int"][0, :n]
+        assert int(st.min()) >= 0 and int(st.max()) < (500 if env_id == L.ENV_TAXI else 704)
+        s = g.stats()
+        if env_id == L.ENV_BLACKJACK:
+            assert s.episodes > n and -1.0 <= s.sum_return / s.episodes <= 0.0 and s.min_return == -1.0 and s.max_return == 1.0
+        else:  # a random policy does not deliver in 24 steps often, and nothing else ends an episode before step 200
+            assert s.max_return <= 20.0 and int(v["state_int"][-1, :n].max()) <= 24
+        g.close()
+
+
 def test_pong_65536_frames(oracle):
     import torch
     n, k, base, width = 65536, 30, 60000, 64
