@@ -85,18 +85,15 @@ struct Acrobot64 {
     dy[0] = w1; dy[1] = w2; dy[2] = a1; dy[3] = a2;
   }
 
-  // Into [-pi, pi] in bounded time.  A step moves an angle by less than two turns (the velocities
-  // are bounded by 9 pi and dt = 0.2), so two single-turn corrections -- each the exact
-  // `x -= two_pi` a loop would make -- cover every state the env itself produces; anything still
-  // outside (a huge angle written by a caller) is reduced in one multiply-add, and a non-finite
-  // value ends as NaN instead of keeping a loop alive.
+  // Into [-pi, pi] in bounded time.  A step moves an angle by less than one turn (the stored velocities
+  // are bounded by 9 pi and dt = 0.2), so one single-turn correction -- the exact `x -= two_pi` (or
+  // `+=`) a loop would make, as five instructions: the turn takes the angle's sign -- covers what the env
+  // itself produces; anything still outside (a stage slope beyond the velocity bounds, a huge angle
+  // written by a caller) is reduced in one multiply-add, and a non-finite value ends as NaN instead of
+  // keeping a loop alive.
   static __device__ __forceinline__ double wrap_pi(double x) {
     const double two_pi = 2.0 * M_PI;
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-      if (x > M_PI) x -= two_pi;
-      else if (x < -M_PI) x += two_pi;
-    }
+    if (fabs(x) > M_PI) x -= copysign(two_pi, x);
     if (!(fabs(x) <= M_PI)) x = fma(-two_pi, rint(x * (1.0 / two_pi)), x);
     return x;
   }
