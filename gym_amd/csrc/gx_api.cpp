@@ -624,6 +624,13 @@ extern "C" int gx_vec_create(gx_ctx* ctx, const gx_desc* desc, gx_vec** out) {
   v->is_frame = env == GX_ENV_PONG || env == GX_ENV_BREAKOUT || env == GX_ENV_SPACEINVADERS;
   v->envs_per_lane = (v->is_acrobot64 || v->is_classic64) ? 2 : (v->is_frame ? 1 : 4);
   v->stride = (v->n + 3) & ~3ull;  // rows stay 16-byte aligned for every element width
+  // Classic control: rows of a large batch that would lie an exact multiple of 64 KiB apart (16 Mi envs: 64 MiB)
+  // are moved off that power of two by 256 elements (measured at 16 Mi envs: CartPole 0.144 -> 0.140 ms, MountainCar
+  // 0.0884 -> 0.0863, the others 0.8-1.7 % faster; any pad from 256 to 768 elements does, 64 are slower than none).
+  // The table-driven envs gain nothing from it (-1.2 to +0.8 %) and keep their rows as they are.
+  // GYMX_ROW_PAD (elements) overrides for every env: a tuning aid.
+  if (const char* s = std::getenv("GYMX_ROW_PAD")) v->stride += (uint64_t)std::atoll(s) & ~3ull;
+  else if (v->is_classic && v->stride >= (1u << 16) && (v->stride & 0x3FFFu) == 0) v->stride += 256;
   v->ep_return_f64 = env == GX_ENV_MOUNTAINCAR_CONT || env == GX_ENV_PENDULUM;
   fill_info(v);
 
