@@ -1195,7 +1195,9 @@ extern "C" int gx_rows_step(gx_ctx* c, const gx_rows* r, int k_steps, void* stre
   // the geometry gx_vec_create gives the same batch, within the slots the scratch array holds
   const uint64_t groups = (r->num_envs + 3) / 4;
   const uint64_t blocks = (groups + kClassicBlock - 1) / kClassicBlock;
-  const uint64_t cap = std::max<uint64_t>((blocks + 1) / 2, (uint64_t)c->num_cus * 4);
+  uint64_t cap = std::max<uint64_t>((blocks + 1) / 2, (uint64_t)c->num_cus * 4);
+  const uint64_t resident = (uint64_t)c->num_cus * 32;
+  if (k_steps == 1 && cap >= 2 * resident && cap < blocks) cap = (cap / resident) * resident + resident * 4 / 9;  // as gx_vec_create
   const dim3 grid((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min(blocks, cap), (uint64_t)kRowsMaxSlots)));
   const int num_slots = std::max((int)grid.x * (kClassicBlock / 64), kBlock / 64);
 

@@ -139,7 +139,8 @@ typedef struct gx_info {
 /* Device pointers for on-GPU agents (zero-copy path). */
 typedef struct gx_view {
   uint64_t num_envs;
-  uint64_t stride;    /* elements between consecutive component arrays (>= num_envs) */
+  uint64_t stride;    /* elements between consecutive component arrays: a multiple of 4, >= num_envs, and for
+                         large batches more than num_envs rounded up (rows are kept off power-of-two spacings) */
   void* state_real;   /* [n_real][stride] float or double; for reading -- a state is written with gx_vec_set_state
                          (Acrobot in GX_MODE_EXACT keeps two rows of derived angles behind these, which a write
                          that bypasses gx_vec_set_state would leave stale) */
