@@ -769,3 +769,34 @@ def test_frames_of_a_batch_rastered_in_several_launches():
         return r.stdout.split()
     whole, sliced = digests(0), digests(24)
     assert len(whole) == 3 and whole == sliced
+
+
+@pytest.mark.parametrize("env_id", [L.ENV_CARTPOLE, L.ENV_PENDULUM])
+def test_rows_kept_off_power_of_two_spacing(oracle, env_id):
+    """a classic-control batch whose rows would lie a multiple of 64 KiB apart gets a longer stride (and its row
+    arrays staggered starts): every path that walks the rows -- steps, host copies, state images, views -- must
+    follow the stride the view reports"""
+    n = 1 << 16
+    flags = L.AUTORESET | L.RECORD_STATS
+    g, o = make_pair(oracle, env_id, n, seed=31, flags=flags)
+    assert int(g.view().stride) == n + 256
+    g.reset(); o.reset()
+    rng = np.random.default_rng(9)
+    for t in range(12):
+        if t % 2:
+            g.step_random(); g.ctx.synchronize()
+            o.step_random()
+        else:
+            a = random_actions(rng, env_id, n)
+            obs, rew, done, _ = g.step_host(a, want_obs=True)
+            orew, odone, _ = o.step(a)
+            assert np.array_equal(done, odone) and np.array_equal(bits(obs), bits(o.get_obs()))
+            assert np.array_equal(rew.astype(np.float64), orew)
+    gr, gi = g.get_state(); orr, oi = o.get_state()
+    assert np.array_equal(bits(gr), bits(orr)) and np.array_equal(gi, oi)
+    # a state image written back lands in the same rows
+    g.set_state(gr, gi)
+    g2r, g2i = g.get_state()
+    assert np.array_equal(bits(g2r), bits(gr)) and np.array_equal(g2i, gi)
+    s, so = g.stats(), o.stats()
+    assert s.episodes == so.episodes and s.sum_length == so.sum_length
