@@ -638,6 +638,10 @@ extern "C" int gx_vec_create(gx_ctx* ctx, const gx_desc* desc, gx_vec** out) {
   else if (v->is_classic && v->stride >= (1u << 16) && (v->stride & 0x3FFFu) == 0) {
     v->stride += 256;
     v->row_skew = 1024;  // and the separately allocated row arrays continue the 1 KiB staircase (see rows_alloc below)
+  } else if (v->is_tabular && !v->is_blackjack && v->stride >= (1u << 16) && (v->stride & 0x3FFFu) == 0) {
+    // the table-driven envs keep their stride (see above) but start their row arrays 4 KiB apart: full Taxi-v3, which
+    // has a return row more than the others, steps 64 Mi envs in 0.343 instead of 0.357 ms; the others -0.1 to -0.3 %
+    v->row_skew = 4096;
   }
   v->ep_return_f64 = env == GX_ENV_MOUNTAINCAR_CONT || env == GX_ENV_PENDULUM;
   fill_info(v);
