@@ -43,13 +43,19 @@ def _gpus_from_argv(argv):
     return 1
 
 
-def spawn_ranks(world, argv):
+def spawn_ranks(world, argv, script=None, grace=None):
     """One child process per rank, each a fresh interpreter that initialises its own GPU.  Returns
-    the worst exit code.  When a rank fails the others (which would wait for it at a barrier for
-    ever) are given a short grace period and then terminated, each by its own PID."""
+    the exit code of the first rank that failed (0 if none did).  Rank 0's standard output is
+    relayed by a thread while ALL children are polled, so a rank that dies at start-up is seen at
+    once: the others (which would wait for it in the rendezvous or at a barrier until torch's own
+    timeout) get `grace` seconds to end by themselves, are then terminated, each by its own PID,
+    and killed ten seconds later if they ignore that."""
     import socket
     import subprocess
+    import threading
 
+    script = script or os.path.abspath(__file__)
+    grace = float(os.environ.get("GYMX_BENCH_GRACE_S", "30")) if grace is None else grace
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -58,27 +64,43 @@ def spawn_ranks(world, argv):
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + list(argv), env=env,
+        procs.append(subprocess.Popen([sys.executable, "-u", script] + list(argv), env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out = procs[0].stdout.read()  # rank 0 is the only one that prints; ends when it exits
-    sys.stdout.write(out.decode("utf-8", "replace"))
-    sys.stdout.flush()
-    worst, deadline = 0, None
-    pending = list(procs)
+
+    def relay():  # rank 0 is the only one that prints; ends when its pipe closes
+        for line in iter(procs[0].stdout.readline, b""):
+            sys.stdout.write(line.decode("utf-8", "replace"))
+            sys.stdout.flush()
+
+    t = threading.Thread(target=relay, daemon=True)
+    t.start()
+    first_bad, deadline, killed_at = 0, None, None
+    pending = dict(enumerate(procs))
     while pending:
-        for p in list(pending):
+        for r, p in list(pending.items()):
             rc = p.poll()
-            if rc is not None:
-                pending.remove(p)
-                if rc != 0:
-                    worst = worst or (rc if rc > 0 else 128 - rc)
-                    deadline = deadline or time.time() + 30.0
-        if pending and deadline and time.time() > deadline:
-            for p in pending:
-                p.terminate()
-            deadline = time.time() + 1e9
+            if rc is None:
+                continue
+            del pending[r]
+            if rc != 0 and deadline is None:
+                first_bad = rc if rc > 0 else 128 - rc
+                deadline = time.time() + grace
+                print("bench.py launcher: rank %d exited with code %d; the other ranks have %.0f s to end"
+                      % (r, rc, grace), file=sys.stderr)
+        now = time.time()
+        if pending and deadline is not None and now > deadline:
+            if killed_at is None:
+                print("bench.py launcher: terminating ranks %s" % sorted(pending), file=sys.stderr)
+                for p in pending.values():
+                    p.terminate()
+                killed_at = now + 10.0
+            elif now > killed_at:
+                for p in pending.values():
+                    p.kill()
+                killed_at = now + 1e9
         time.sleep(0.05)
-    return worst
+    t.join(timeout=5.0)
+    return first_bad
 
 
 if __name__ == "__main__" and "WORLD_SIZE" not in os.environ and _gpus_from_argv(sys.argv[1:]) > 1:
@@ -134,6 +156,7 @@ ACROBOT_RK4_FLOPS = 196
 # (SQ_INSTS_VALU_ADD_F64 + MUL_F64 + TRANS_F64 + 2 FMA_F64) x 64 lanes / (envs x K) of the fused
 # 64-step rollout, profiles/r2/fp64_valu_acrobot_rk4_rollout64.json (tools/fp64_profile.sh)
 ACROBOT_RK4_FLOPS_COUNTED = 533.1
+ACROBOT_RK4_FLOPS_SOURCE = "SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64, profiles/r2/fp64_valu_acrobot_rk4_rollout64.json"
 
 
 def time_steps(batch, step_fn, steps, warmup, dist):
@@ -163,6 +186,51 @@ def time_steps(batch, step_fn, steps, warmup, dist):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     return wall, kernel_ms
+
+
+def join_ranks(rank, world, timeout_s):
+    """Roll call before init_process_group, over the rendezvous store itself: every rank writes its
+    key, rank 0 waits for all of them for at most `timeout_s` and names the ranks that never came
+    (a rank that died at start-up would otherwise only show as a timeout somewhere inside the
+    backend).  Returns the store to build the process group on."""
+    import datetime
+
+    from torch.distributed import PrefixStore, TCPStore
+
+    host, port = os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"])
+    # under torch.distributed.run the launcher's agent already serves a store on this port and every worker,
+    # rank 0 included, is a client of it
+    agent_store = os.environ.get("TORCHELASTIC_USE_AGENT_STORE") == "True"
+    try:
+        store = TCPStore(host, port, world, is_master=(rank == 0 and not agent_store),
+                         timeout=datetime.timedelta(seconds=timeout_s), wait_for_workers=False, multi_tenant=True)
+    except Exception as e:  # noqa: BLE001  (rank 0's store never came up)
+        print("bench.py: rank %d could not reach the rendezvous store at %s:%d within %d s: %s" % (rank, host, port, timeout_s, e),
+              file=sys.stderr)
+        sys.exit(4)
+    store = PrefixStore("gymx_bench", store)
+    store.set("joined/%d" % rank, b"1")
+    if rank == 0:
+        deadline = time.time() + timeout_s
+        missing = list(range(1, world))
+        while missing and time.time() < deadline:
+            missing = [r for r in missing if not store.check(["joined/%d" % r])]
+            if missing:
+                time.sleep(0.05)
+        if missing:
+            print("bench.py: ranks %s of %d did not join within %d s" % (missing, world, timeout_s), file=sys.stderr)
+            store.set("go", b"0")
+            sys.exit(4)
+        store.set("go", b"1")
+    else:
+        try:
+            store.wait(["go"], datetime.timedelta(seconds=timeout_s))
+        except Exception:  # noqa: BLE001
+            print("bench.py: rank %d waited %d s for the roll call of rank 0" % (rank, timeout_s), file=sys.stderr)
+            sys.exit(4)
+        if store.get("go") != b"1":
+            sys.exit(4)
+    return store
 
 
 def cpu_baseline(env_name, target_seconds=12.0):
@@ -219,6 +287,67 @@ def d2d_copy_rate(nbytes=1 << 31, reps=5):
     return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
+def bytes_per_env_step(env, policy, mode="exact", rk4=False, taxi_full=False, blackjack_full=False):
+    """Algorithmic bytes one env-step of the single-step kernel moves (B_ALG's rule)"""
+    if rk4:
+        # f64 state r+w, steps r+w, reward, done, derived f32 observation rows
+        return 32 + 32 + 4 + 4 + 4 + 1 + 24 + (4 if policy == "device" else 0)
+    b = B_ALG[env] + (8 if taxi_full or blackjack_full else 0)
+    if env == "blackjack":
+        b += 4 if blackjack_full and policy != "random" else 0  # only upstream's rules look at the action
+    elif policy == "random":
+        b -= 4
+    if mode == "fp64" and env in B_ALG_FP64_EXTRA:
+        b += B_ALG_FP64_EXTRA[env]
+    return b
+
+
+def device_action_ring(batch, stream_ptr):
+    """A ring of pre-sampled action rows, ActionSpace.Sample() of ticks 0..7, cycled step by step: the policy
+    is random in time as well as across envs, and a step still reads one 4-byte action per env.  Returns the
+    step function (the ring tensor stays alive in its closure)."""
+    adt = torch.float32 if batch.info.action_dtype == L.F32 else torch.int32
+    ring = torch.empty((ACTION_RING, int(batch.view().stride)), dtype=adt, device="cuda")
+    for t in range(ACTION_RING):
+        batch.sample_actions(t, ring[t].data_ptr(), stream_ptr)
+    ring_ptrs = [ring[t].data_ptr() for t in range(ACTION_RING)]
+    turn = [0]
+
+    def step_fn(_keep=ring):
+        batch.step_device(ring_ptrs[turn[0] % ACTION_RING], stream_ptr)
+        turn[0] += 1
+
+    return step_fn
+
+
+def rank_evidence(dist, backend, rank, world, local_rank, kernel_ms):
+    """What shows that the job really had `world` ranks on `world` devices: every rank's device and kernel
+    time (gathered over the collective backend itself) and the time of one statistics all-reduce."""
+    prop = torch.cuda.get_device_properties(local_rank)
+    mine = {"rank": rank, "local_rank": local_rank, "device": prop.name,
+            "pci_bus_id": getattr(prop, "pci_bus_id", None), "kernel_ms": kernel_ms, "pid": os.getpid()}
+    if dist is None:
+        return {"world": 1, "backend": None, "per_rank_kernel_ms": [kernel_ms], "per_rank": [mine], "allreduce_us": None}
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    # the collective of the data path: two tiny all-reduces (sums, extrema) per statistics record
+    sums = torch.zeros(4, dtype=torch.float64, device=COLLECTIVE_DEVICE)
+    ext = torch.zeros(2, dtype=torch.float64, device=COLLECTIVE_DEVICE)
+    reps = 20
+    for timed in (False, True):
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+            dist.all_reduce(ext, op=dist.ReduceOp.MAX)
+        torch.cuda.synchronize()
+        us = (time.perf_counter() - t0) / reps * 1e6
+    return {"world": world, "backend": "rccl (torch nccl)" if backend == "nccl" else backend,
+            "per_rank_kernel_ms": [e["kernel_ms"] for e in everyone], "per_rank": everyone,
+            "allreduce_us": us, "allreduce_what": "one statistics record: all_reduce(sum, 4 x f64) + all_reduce(max, 2 x f64), mean of %d" % reps}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -243,19 +372,29 @@ def main():
                     help="with --rollout K: what the fused rollout hands back -- the last step's reward / done rows, every "
                          "step's (written to [K][stride] device rows, 5 or 9 more bytes per env-step), or statistics only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the secondary Acrobot measurements")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurements (the other named workloads)")
+    ap.add_argument("--extra-envs-scale", type=float, default=1.0,
+                    help="tests only: scales the env counts of the secondary measurements")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl is RCCL on ROCm; gloo only to rehearse several ranks on one GPU")
     ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses GPU local_rank %% device_count")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: initialise torch.distributed even for one rank (exercises the RCCL barrier / all-reduce path)")
+    ap.add_argument("--join-timeout", type=int, default=120,
+                    help="seconds a rank waits for the others at start-up (roll call and process-group initialisation)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("GYMX_BENCH_FAIL_RANK") == str(rank):
+        # fault injection for the launcher's test: this rank dies before it joins anything
+        print("bench.py: rank %d leaves at start-up (GYMX_BENCH_FAIL_RANK)" % rank, file=sys.stderr)
+        sys.exit(3)
     dist = None
     if world > 1 or args.force_dist:
+        import datetime
+
         import torch.distributed as dist_mod
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -263,10 +402,17 @@ def main():
         if args.share_device:
             local_rank %= torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
+        store = join_ranks(rank, world, args.join_timeout)
         # naming the device binds the RCCL communicator to this rank's GPU up front (no guessing at
         # the first barrier)
         kw = {"device_id": torch.device("cuda", local_rank)} if args.dist_backend == "nccl" else {}
-        dist_mod.init_process_group(args.dist_backend, rank=rank, world_size=world, **kw)
+        try:
+            dist_mod.init_process_group(args.dist_backend, store=store, rank=rank, world_size=world,
+                                        timeout=datetime.timedelta(seconds=args.join_timeout), **kw)
+        except Exception as e:  # noqa: BLE001
+            print("bench.py: rank %d of %d could not initialise the %s process group within %d s: %s"
+                  % (rank, world, args.dist_backend, args.join_timeout, e), file=sys.stderr)
+            sys.exit(5)
         dist = dist_mod
         global COLLECTIVE_DEVICE
         COLLECTIVE_DEVICE = "cuda" if args.dist_backend == "nccl" else "cpu"
@@ -322,19 +468,7 @@ def main():
                 torch.cuda.current_stream().synchronize()
                 allreduce_stats(batch.stats(), dist, device=COLLECTIVE_DEVICE)
     elif args.policy == "device":
-        # a ring of pre-sampled action rows, ActionSpace.Sample() of ticks 0..7, cycled step by step:
-        # the policy is random in time as well as across envs, and a step still reads one 4-byte
-        # action per env
-        adt = torch.float32 if batch.info.action_dtype == L.F32 else torch.int32
-        ring = torch.empty((ACTION_RING, int(view.stride)), dtype=adt, device="cuda")
-        for t in range(ACTION_RING):
-            batch.sample_actions(t, ring[t].data_ptr(), stream_ptr)
-        ring_ptrs = [ring[t].data_ptr() for t in range(ACTION_RING)]
-        turn = [0]
-
-        def step_fn():
-            batch.step_device(ring_ptrs[turn[0] % ACTION_RING], stream_ptr)
-            turn[0] += 1
+        step_fn = device_action_ring(batch, stream_ptr)
     else:
         step_fn = lambda: batch.step_random(stream_ptr)  # noqa: E731
     torch.cuda.synchronize()
@@ -351,17 +485,7 @@ def main():
     total_steps = n * world * args.steps * k_roll
     value = total_steps / wall
 
-    if args.rk4:
-        # f64 state r+w, steps r+w, reward, done, derived f32 observation rows
-        b_alg = 32 + 32 + 4 + 4 + 4 + 1 + 24
-    else:
-        b_alg = B_ALG[args.env] + (8 if args.taxi_full or args.blackjack_full else 0)
-        if args.env == "blackjack":
-            b_alg += 4 if args.blackjack_full and args.policy != "random" else 0  # only upstream's rules look at the action
-        elif args.policy == "random":
-            b_alg -= 4
-        if fp64_state:
-            b_alg += B_ALG_FP64_EXTRA[args.env]
+    b_alg = bytes_per_env_step(args.env, args.policy, args.mode, args.rk4, args.taxi_full, args.blackjack_full)
     if k_roll > 1:
         # per env-step of a K-step rollout: the rows are read and written once per launch; the last step's reward /
         # done rows, or every step's
@@ -387,10 +511,11 @@ def main():
             "envs_per_gpu": n, "sharding": "independent env shards, no data-path collective",
             "settle_steps_after_reset": args.settle if k_roll == 1 else 0,
         },
+        # per GPU and per launch on every line: rank 0's kernel on rank 0's shard (the shards are the same size)
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                      "kernel_ms": kernel_ms, "bytes_per_env_step": b_alg,
-                     "algorithmic_bytes_per_launch": b_alg * n * k_roll},
+                     "algorithmic_bytes_per_launch": b_alg * n * k_roll, "scope": "one GPU (rank 0), one launch"},
     }
     if args.rk4 and k_roll > 1:
         # the fused rollout is bound by the FP64 vector ALU, not by HBM: flops as the SQ counters
@@ -400,12 +525,13 @@ def main():
                            "frac": tf / FP64_VALU_PEAK_TFLOPS, "traffic": None, "kernel_ms": kernel_ms,
                            "fp64_flops_per_env_step": ACROBOT_RK4_FLOPS_COUNTED,
                            "arithmetic_only_flops_per_env_step": ACROBOT_RK4_FLOPS,
-                           "source": "SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64, profiles/r2/fp64_valu_acrobot_rk4_rollout64.json"}
+                           "source": ACROBOT_RK4_FLOPS_SOURCE, "scope": "one GPU (rank 0), one launch"}
     # HBM bytes per launch from the rocprofv3 counter passes (FETCH_SIZE doubled as gfx950
-    # needs, WRITE_SIZE as read) of this same command, taken by tools/collect_profiles.sh and
-    # committed under profiles/; counters cannot be read from inside this process.
+    # needs, WRITE_SIZE as read) of this same command on one GPU, taken by tools/collect_profiles.sh and
+    # committed under profiles/; counters cannot be read from inside this process.  A rank of a larger job
+    # launches the same kernel on a shard of the same size, so the figure holds per GPU at every N.
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(traffic_file) and world == 1:
+    if os.path.exists(traffic_file):
         try:
             from gym_amd.build import csrc_hash
 
@@ -413,8 +539,9 @@ def main():
             if t and not args.rk4 and k_roll == 1 and not (args.slippery or args.taxi_full or args.blackjack_full or args.map or args.mode != "exact"):
                 if t.get("csrc_hash") == csrc_hash():
                     out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
-                    out["roofline"]["traffic_source"] = t["source"]
-                else:
+                    out["roofline"]["traffic_source"] = t["source"] + (
+                        "; counters taken on one GPU, the kernel and the shard size are the same on every rank" if world > 1 else "")
+                elif rank == 0:
                     # counters taken on other kernel sources say nothing about this build
                     print("note: profiles/traffic.json was measured on kernel sources %s, this build is %s; traffic left null"
                           % (t.get("csrc_hash"), csrc_hash()), file=sys.stderr)
@@ -426,61 +553,82 @@ def main():
     out["episode_stats"] = {"episodes": ep["episodes"], "mean_length": ep["sum_length"] / max(ep["episodes"], 1),
                             "mean_return": ep["sum_return"] / max(ep["episodes"], 1),
                             "min_return": ep["min_return"], "max_return": ep["max_return"]}
+    out["ranks"] = rank_evidence(dist, args.dist_backend, rank, world, local_rank, kernel_ms)
+    batch.close()
 
     if not args.no_extra and args.env == "cartpole":
         # every rank takes part: the timings are maxima over ranks, the rollout all-reduces its statistics
-        extra = extra_measurements(ctx, n, stream_ptr, dist, rank, world)
+        extra = extra_measurements(ctx, n, stream_ptr, dist, rank, world, args.extra_envs_scale)
         if rank == 0:
             out["extra"] = extra
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank != 0:
+        return
+    # The CPU legs come last, at every N, on rank 0 alone: the other ranks have left by now, so the host cores
+    # are as free as in the one-GPU run.
+    if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.env)
         if args.slippery or args.taxi_full or args.blackjack_full or args.rk4:
             out["cpu_baseline"]["sample"] += "; the CPU loop runs the reference's own rules, not the extension timed on the GPU"
         allc = cpu_baseline_all_cores(args.env)
         if allc:
             out["cpu_baseline_all_cores"] = allc
-    if rank == 0:
-        print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    print(json.dumps(out))
 
 
-def extra_measurements(ctx, n, stream_ptr, dist, rank, world):
-    """Secondary numbers named by the headline metric: Acrobot single-step (reference dynamics)
-    and the fused 64-step RK4/binary64 rollout (FP64 vector-ALU bound), n envs per rank.  Rates are
-    whole-job (all ranks' env-steps over the slowest rank's wall time between barriers); the
-    kernel times are rank 0's, from HIP events."""
+def measure_single_step(ctx, env, n, stream_ptr, dist, rank, world, policy="device", mode="exact", flags_extra=0,
+                        map_rows=None, steps=100, settle=100, seed=1):
+    """One named workload under the same clock as the headline: n envs per rank, `settle` untimed steps after
+    Reset(), `steps` timed between barriers.  Rates are whole-job (all ranks' env-steps over the slowest
+    rank's wall time); the kernel time is rank 0's, from HIP events on the launch stream."""
+    flags = L.AUTORESET | L.RECORD_STATS | flags_extra
+    b = DeviceBatch(ctx, ENV_IDS[env], n, seed=seed, flags=flags, env_index_base=rank * n, map_rows=map_rows,
+                    mode={"exact": L.MODE_EXACT, "fast32": L.MODE_FAST32, "fp64": L.MODE_FP64}[mode])
+    b.reset()
+    step_fn = device_action_ring(b, stream_ptr) if policy == "device" else (lambda: b.step_random(stream_ptr))
+    wall, ms = time_steps(b, step_fn, steps, settle, dist)
+    b_alg = bytes_per_env_step(env, policy, mode, bool(flags_extra & L.ACROBOT_RK4), bool(flags_extra & L.TAXI_FULL),
+                               bool(flags_extra & L.BLACKJACK_FULL))
+    gbps = b_alg * n / (ms * 1e-3) / 1e9
+    res = {"env_steps_per_s": n * world * steps / wall, "n_gpus": world, "envs_per_gpu": n, "kernel_ms": ms,
+           "bytes_per_env_step": b_alg, "hbm_GBps_per_gpu": gbps, "frac": gbps / HBM_PEAK_GBPS,
+           "actions": "device row" if policy == "device" else "sampled in-kernel", "mode": mode,
+           "untimed_steps_after_reset": settle, "timed_steps": steps}
+    del step_fn
+    b.close()
+    return res
+
+
+def extra_measurements(ctx, n, stream_ptr, dist, rank, world, scale=1.0):
+    """The other workloads the metric and the benchmark configurations name, each timed like the headline
+    (barriers, slowest rank, HIP events): CartPole with in-kernel actions, Acrobot single step (reference
+    dynamics), the fused 64-step RK4/binary64 rollout (FP64 vector-ALU bound); MountainCar, MountainCarContinuous
+    and Pendulum at 16 Mi envs in binary32 and binary64; FrozenLake 8x8 slippery and Taxi (the reference's stub
+    and upstream's dynamics) at 64 Mi envs; Pong at 65 536 envs, step + frame raster."""
     res = {}
     if world == 1:
         res["hbm_copy_ceiling_GBps_measured"] = d2d_copy_rate()
-    flags = L.AUTORESET | L.RECORD_STATS
-    base = rank * n
+
+    def envs(count):
+        return max(4096, int(count * scale) // 4096 * 4096)
+
+    def m(key, *a, **kw):
+        res[key] = measure_single_step(ctx, *a, stream_ptr=stream_ptr, dist=dist, rank=rank, world=world, **kw)
+
     # the headline workload with the actions sampled in the kernel (Spaces.Discrete.Sample per env and step on the
     # device) instead of read from a device row: 45 B per env-step
-    b = DeviceBatch(ctx, L.ENV_CARTPOLE, n, seed=1, flags=flags, env_index_base=base)
-    b.reset()
-    steps, settle = 100, 150
-    wall, ms = time_steps(b, lambda: b.step_random(stream_ptr), steps, settle, dist)
-    res["cartpole_actions_sampled_in_kernel"] = {"env_steps_per_s": n * world * steps / wall, "n_gpus": world, "kernel_ms": ms,
-                                                 "hbm_GBps_per_gpu": (B_ALG["cartpole"] - 4) * n / (ms * 1e-3) / 1e9,
-                                                 "untimed_steps_after_reset": settle, "timed_steps": steps}
-    b.close()
-    b = DeviceBatch(ctx, L.ENV_ACROBOT, n, seed=1, flags=flags, env_index_base=base)
-    b.reset()
+    m("cartpole_actions_sampled_in_kernel", "cartpole", n, policy="random", settle=150)
     # The cost of a fused step depends on how many envs finish in it (every wave with a finished env runs a reset
-    # round).  Reset() fills all six slots with small uniforms (Envs.Acrobot.cs:24-25), i.e. both angles are
+    # round).  Acrobot's Reset() fills all six slots with small uniforms (Envs.Acrobot.cs:24-25), i.e. both angles are
     # uniform on the circle, so the first steps after it end a large share of the episodes at once; the rate
     # settles at 0.2-0.4 % of the envs per step after a few hundred steps (tools/step_time_series.py: 0.29 ms
     # per step over the first 50 steps, 0.23-0.24 ms from step 150 on).  Timed in that stationary regime.
-    steps, settle = 100, 300
-    wall, ms = time_steps(b, lambda: b.step_random(stream_ptr), steps, settle, dist)
-    res["acrobot_euler_exact_single_step"] = {"env_steps_per_s": n * world * steps / wall, "n_gpus": world, "kernel_ms": ms,
-                                             "hbm_GBps_per_gpu": (B_ALG["acrobot"] - 4) * n / (ms * 1e-3) / 1e9,
-                                             "untimed_steps_after_reset": settle, "timed_steps": steps}
-    b.close()
+    m("acrobot_euler_exact_single_step", "acrobot", n, policy="random", settle=300)
+    m("acrobot_euler_exact_single_step_device_actions", "acrobot", n, policy="device", settle=300)
     k = 64
-    b = DeviceBatch(ctx, L.ENV_ACROBOT, n, seed=1, flags=flags | L.ACROBOT_RK4, env_index_base=base)
+    b = DeviceBatch(ctx, L.ENV_ACROBOT, n, seed=1, flags=L.AUTORESET | L.RECORD_STATS | L.ACROBOT_RK4, env_index_base=rank * n)
     b.reset()
 
     def rollout():
@@ -497,8 +645,21 @@ def extra_measurements(ctx, n, stream_ptr, dist, rank, world):
                                          "env_steps_per_s_per_gpu_kernel": rate, "kernel_ms": ms,
                                          "fp64_TFLOPs": rate * ACROBOT_RK4_FLOPS_COUNTED / 1e12,
                                          "frac_of_fp64_valu_peak": rate * ACROBOT_RK4_FLOPS_COUNTED / 1e12 / FP64_VALU_PEAK_TFLOPS,
-                                         "fp64_TFLOPs_arith_only": rate * ACROBOT_RK4_FLOPS / 1e12}
+                                         "fp64_TFLOPs_arith_only": rate * ACROBOT_RK4_FLOPS / 1e12,
+                                         "stats_allreduced_after_every_rollout": dist is not None}
     b.close()
+    # classic control, 16 Mi envs per GPU, binary32 (EXACT) and binary64 state
+    for env in ("mountaincar", "mountaincarcontinuous", "pendulum"):
+        for mode in ("exact", "fp64"):
+            m("%s_%s" % (env, mode), env, n, mode=mode)
+    # table-driven envs, 64 Mi envs per GPU, tables staged in LDS
+    big = envs(4 * n)
+    for policy, tag in (("device", "device_actions"), ("random", "in_kernel_actions")):
+        m("frozenlake_8x8_slippery_64Mi_" + tag, "frozenlake", big, policy=policy, flags_extra=L.SLIPPERY, map_rows="8x8")
+        m("taxi_stub_64Mi_" + tag, "taxi", big, policy=policy)
+        m("taxi_v3_full_64Mi_" + tag, "taxi", big, policy=policy, flags_extra=L.TAXI_FULL)
+    # Pong: game step + 210x160x3 frame raster per env-step
+    m("pong_step_and_raster", "pong", envs(65536), settle=20)
     return res
 
 

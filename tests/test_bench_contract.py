@@ -49,7 +49,13 @@ def test_plain_launch_with_two_ranks():
     """`python bench.py --gpus 2` with no launcher around it starts its own two ranks (here both on the one GPU of
     the test box, collectives over gloo) and prints one line for the whole job"""
     j = _run("--gpus", "2", "--share-device", "--dist-backend", "gloo", "--num-envs", "262144", "--no-extra")
-    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and "cpu_baseline" not in j
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak"
+    # the CPU leg and the per-GPU roofline are on the line at every N, and the line shows its ranks
+    assert j["cpu_baseline"]["cores"] == 1 and j["cpu_baseline"]["value"] > 0
+    assert "traffic" in j["roofline"] and j["roofline"]["scope"].startswith("one GPU")
+    rk = j["ranks"]
+    assert rk["world"] == 2 and rk["backend"] == "gloo" and len(rk["per_rank_kernel_ms"]) == 2 and rk["allreduce_us"] > 0
+    assert sorted(e["rank"] for e in rk["per_rank"]) == [0, 1] and len({e["pid"] for e in rk["per_rank"]}) == 2
     # whole-job value: both ranks' envs over the slowest rank's time
     assert abs(j["value"] - 2 * 262144 * 5 / (j["ms_per_step"] * 5e-3)) / j["value"] < 1e-6
     assert j["episode_stats"]["episodes"] >= 0  # six steps: no CartPole episode is over yet
@@ -84,3 +90,67 @@ def test_launched_by_torch_distributed_run_with_two_ranks():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["scaling"] == "weak"
     assert abs(j["value"] - 2 * 262144 * 5 / (j["ms_per_step"] * 5e-3)) / j["value"] < 1e-6
+
+
+@pytest.mark.gpu
+def test_a_rank_that_dies_at_start_up_ends_the_job_quickly():
+    """rank 1 leaves before it joins anything: the launcher sees it, gives rank 0 its grace period and ends it; the
+    whole call returns rank 1's exit code well within a minute instead of waiting for a collective's timeout"""
+    import time
+
+    env = dict(os.environ, GYMX_BENCH_FAIL_RANK="1", GYMX_BENCH_GRACE_S="10")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1",
+                        "--share-device", "--dist-backend", "gloo", "--num-envs", "262144", "--no-extra"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    took = time.time() - t0
+    assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
+    assert took < 60.0, took
+    assert "rank 1 exited with code 3" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+@pytest.mark.gpu
+def test_roll_call_alone_names_the_missing_rank():
+    """the same failure without the launcher's help (as under another launcher that does not watch its children):
+    rank 0 names the rank that never came when its own timeout runs out"""
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1",
+                        "--share-device", "--dist-backend", "gloo", "--num-envs", "262144", "--no-extra", "--join-timeout", "3"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 4 and "ranks [1] of 2 did not join within 3 s" in r.stderr, r.stderr[-2000:]
+
+
+EXTRA_KEYS = ["cartpole_actions_sampled_in_kernel", "acrobot_euler_exact_single_step", "acrobot_euler_exact_single_step_device_actions",
+              "acrobot_rk4_fp64_rollout64",
+              "mountaincar_exact", "mountaincar_fp64", "mountaincarcontinuous_exact", "mountaincarcontinuous_fp64",
+              "pendulum_exact", "pendulum_fp64",
+              "frozenlake_8x8_slippery_64Mi_device_actions", "frozenlake_8x8_slippery_64Mi_in_kernel_actions",
+              "taxi_stub_64Mi_device_actions", "taxi_stub_64Mi_in_kernel_actions",
+              "taxi_v3_full_64Mi_device_actions", "taxi_v3_full_64Mi_in_kernel_actions", "pong_step_and_raster"]
+
+
+@pytest.mark.gpu
+def test_extra_carries_every_named_configuration():
+    """the secondary measurements (every workload the benchmark configurations name) at a hundredth of their size"""
+    j = _run("--num-envs", "262144", "--no-cpu-baseline", "--extra-envs-scale", "0.0625")
+    ex = j["extra"]
+    for key in EXTRA_KEYS:
+        assert key in ex, key
+        assert ex[key]["kernel_ms"] > 0 and ex[key]["env_steps_per_s"] > 0
+        if key != "acrobot_rk4_fp64_rollout64":
+            e = ex[key]
+            assert abs(e["frac"] - e["bytes_per_env_step"] * e["envs_per_gpu"] / (e["kernel_ms"] * 1e-3) / 8e12) < 1e-9
+    assert ex["mountaincar_exact"]["bytes_per_env_step"] == 33 and ex["mountaincar_fp64"]["bytes_per_env_step"] == 49
+    assert ex["pendulum_exact"]["bytes_per_env_step"] == 61 and ex["pendulum_fp64"]["bytes_per_env_step"] == 85
+    assert ex["mountaincarcontinuous_exact"]["bytes_per_env_step"] == 53
+    assert ex["frozenlake_8x8_slippery_64Mi_in_kernel_actions"]["bytes_per_env_step"] == 21
+    assert ex["taxi_v3_full_64Mi_device_actions"]["bytes_per_env_step"] == 33
+    assert ex["taxi_stub_64Mi_device_actions"]["envs_per_gpu"] == 65536
+    assert ex["pong_step_and_raster"]["bytes_per_env_step"] == 100937 and ex["pong_step_and_raster"]["envs_per_gpu"] == 4096
