@@ -7,6 +7,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -51,7 +52,7 @@ struct gx_ctx {
   hipEvent_t ev_in = nullptr;
   hipEvent_t ev_out = nullptr;
   char* scratch = nullptr;  // this device's copy of g_rows_scratch (gx_rows_step)
-  int live_handles = 0;     // batches and communicators created on this context and not yet destroyed
+  std::atomic<int> live_handles{0};  // batches and communicators created on this context and not yet destroyed (distinct handles may be driven from distinct threads)
 };
 
 struct gx_vec {
@@ -107,7 +108,11 @@ struct gx_vec {
   // set by set_state: the state may violate the invariants the BOUNDED kernels rely on
   // until one step with auto-reset has run
   bool state_dirty = false;
-  hipStream_t last_stream = nullptr;  // the stream of the most recent step launch (gx_vec_wait orders itself after it)
+  // A caller's own stream is never kept: it may be destroyed the moment the caller has synchronised it.  A step
+  // launched on one whose outcome a later call of the library must wait for (the invalid-action flag; a launch that
+  // reads caller-supplied draws) is followed on that stream by a record of this event, which the library owns.
+  hipEvent_t ev_foreign = nullptr;
+  bool foreign_pending = false;  // ev_foreign was recorded after the most recent such launch
   uint32_t sweep_parity = 0;  // flips every step launch: alternate launches sweep in opposite directions
   // the open-episode return is ret_per_step x the step counter and its row is not maintained
   // (fused auto-reset + statistics on CartPole, MountainCar, Acrobot); ends at the first set_state
@@ -154,10 +159,13 @@ extern "C" int gx_device_count(int* count) {
 // the array's name as an address: gx_ctx_create asks the runtime for this device's copy once
 // and keeps the pointer in the context.
 constexpr uint64_t kRowsMaxEnvs = GX_ROWS_MAX_ENVS;
-constexpr int kRowsMaxSlots = 32768;  // waves of the largest grid: 2^24 envs / 4 per lane / 64 lanes / 2 trips
+// One record per wave of the largest grid gx_vec_create gives a batch of GX_ROWS_MAX_ENVS envs: 2^24 envs / 4 per
+// lane / 64 lanes = 65 536 one-wave workgroups' worth of work, run as 4 4/9 rounds of the 8 192 workgroups a 256-CU
+// part holds at once = 36 408 workgroups; 40 960 leaves room for parts with other CU counts (the grid is clamped to it).
+constexpr int kRowsMaxSlots = 40960;
 constexpr size_t kRowsResultOffset = (size_t)kRowsMaxSlots * sizeof(StatSlot);
 constexpr size_t kRowsErrorOffset = kRowsResultOffset + sizeof(StatSlot);
-constexpr size_t kRowsScratchBytes = kRowsErrorOffset + 256;  // 2 MiB + 320 bytes
+constexpr size_t kRowsScratchBytes = kRowsErrorOffset + 256;  // 2.5 MiB + 320 bytes
 static __device__ __align__(256) unsigned char g_rows_scratch[kRowsScratchBytes];
 
 // ------------------------------------------------------------------ context ---
@@ -201,7 +209,7 @@ extern "C" int gx_ctx_destroy(gx_ctx* c) {
   if (!c) return GX_OK;
   // a batch's destructor synchronises this context's streams: the context must outlive it
   if (c->live_handles > 0)
-    return fail(GX_ERR_INVALID, "gx_ctx_destroy: %d batch(es) / communicator(s) of this context are still alive; destroy them first", c->live_handles);
+    return fail(GX_ERR_INVALID, "gx_ctx_destroy: %d batch(es) / communicator(s) of this context are still alive; destroy them first", c->live_handles.load());
   (void)hipSetDevice(c->device);
   if (c->ev_in) (void)hipEventDestroy(c->ev_in);
   if (c->ev_out) (void)hipEventDestroy(c->ev_out);
@@ -503,6 +511,19 @@ StepArgs make_args(const gx_vec* v, const void* d_actions, int k_steps, uint64_t
   return a;
 }
 
+// Only Acrobot has actions the reference throws on (Envs.Acrobot.cs:45,51); the host path
+// validates them before launch, so the device flag matters for the zero-copy path alone.
+bool has_error_flag(const gx_vec* v) { return v->desc.env_id == GX_ENV_ACROBOT; }
+
+// waits for the most recent launch on a caller's stream that the library has to order itself after
+int wait_foreign(gx_vec* v) {
+  if (v->foreign_pending) {
+    HIP_TRY(hipEventSynchronize(v->ev_foreign));
+    v->foreign_pending = false;
+  }
+  return GX_OK;
+}
+
 // per-step output rows of a rollout (gx_vec_rollout_out)
 struct StepOut {
   void* reward = nullptr;
@@ -540,7 +561,10 @@ int launch_step(gx_vec* v, const void* d_actions, int k_steps, uint64_t action_s
   v->forced_pending = false;
   v->state_dirty = false;
   v->sweep_parity ^= 1u;
-  v->last_stream = stream;
+  if (stream != v->ctx->compute && (a.forced_draws || (has_error_flag(v) && policy == GX_POLICY_DEVICE_ACTIONS))) {
+    HIP_TRY(hipEventRecord(v->ev_foreign, stream));
+    v->foreign_pending = true;
+  }
   return GX_OK;
 }
 
@@ -588,6 +612,7 @@ extern "C" int gx_vec_destroy(gx_vec* v) {
   if (v->h_error) (void)hipHostFree(v->h_error);
   if (v->h_stage) (void)hipHostFree(v->h_stage);
   if (v->h_stat) (void)hipHostFree(v->h_stat);
+  if (v->ev_foreign) (void)hipEventDestroy(v->ev_foreign);
   if (v->ctx) v->ctx->live_handles--;
   delete v;
   return GX_OK;
@@ -692,6 +717,7 @@ extern "C" int gx_vec_create(gx_ctx* ctx, const gx_desc* desc, gx_vec** out) {
   VEC_TRY(rows_alloc((void**)&v->d_done, v->stride, 1));
   if (desc->time_limit > 0) VEC_TRY(rows_alloc((void**)&v->d_trunc, v->stride, 1));
   VEC_TRY(rows_alloc(&v->d_actions, v->stride * 4, 1));
+  VEC_TRY(hipEventCreateWithFlags(&v->ev_foreign, hipEventDisableTiming));
   VEC_TRY(hipMalloc((void**)&v->d_error, 256));
   VEC_TRY(hipMemset(v->d_error, 0, 256));
   VEC_TRY(hipHostMalloc((void**)&v->h_error, 64, hipHostMallocDefault));
@@ -933,8 +959,9 @@ extern "C" int gx_vec_set_rng_draws(gx_vec* v, const double* u, size_t count) {
     }
   }
   HIP_TRY(hipStreamSynchronize(c->compute));  // a launch that still reads the previous draws
-  if (v->last_stream && v->last_stream != c->compute) HIP_TRY(hipStreamSynchronize(v->last_stream));
-  int rc = copy_rows(v->d_forced, u, sizeof(double), (int)per_env, v->n, v->stride, v->n, hipMemcpyHostToDevice, c->copy);
+  int rc = wait_foreign(v);
+  if (rc) return rc;
+  rc = copy_rows(v->d_forced, u, sizeof(double), (int)per_env, v->n, v->stride, v->n, hipMemcpyHostToDevice, c->copy);
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(c->copy));
   v->forced_pending = true;
@@ -1052,10 +1079,6 @@ extern "C" int gx_vec_step_async(gx_vec* v, const void* h_actions, void* h_obs, 
   return GX_OK;
 }
 
-// Only Acrobot has actions the reference throws on (Envs.Acrobot.cs:45,51); the host path
-// validates them before launch, so the device flag matters for the zero-copy path alone.
-static bool has_error_flag(const gx_vec* v) { return v->desc.env_id == GX_ENV_ACROBOT; }
-
 extern "C" int gx_vec_wait(gx_vec* v) {
   if (!v) return fail(GX_ERR_INVALID, "gx_vec_wait: null batch");
   gx_ctx* c = v->ctx;
@@ -1066,7 +1089,7 @@ extern "C" int gx_vec_wait(gx_vec* v) {
   }
   HIP_TRY(hipStreamSynchronize(c->compute));
   // steps enqueued on a caller's stream may still be running: the flag is read (and cleared) after them
-  if (v->last_stream && v->last_stream != c->compute) HIP_TRY(hipStreamSynchronize(v->last_stream));
+  if (int rc = wait_foreign(v)) return rc;
   if (has_error_flag(v)) HIP_TRY(hipMemcpyAsync(v->h_error, v->d_error, 4, hipMemcpyDeviceToHost, c->copy));
   HIP_TRY(hipStreamSynchronize(c->copy));
   if (has_error_flag(v) && *v->h_error) {
@@ -1202,8 +1225,11 @@ extern "C" int gx_rows_step(gx_ctx* c, const gx_rows* r, int k_steps, void* stre
   uint64_t cap = std::max<uint64_t>((blocks + 1) / 2, (uint64_t)c->num_cus * 4);
   const uint64_t resident = (uint64_t)c->num_cus * 32;
   if (k_steps == 1 && cap >= 2 * resident && cap < blocks) cap = (cap / resident) * resident + resident * 4 / 9;  // as gx_vec_create
-  const dim3 grid((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min(blocks, cap), (uint64_t)kRowsMaxSlots)));
+  // the clamp is on statistics records, one per wave, not on workgroups
+  const dim3 grid((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min(blocks, cap), (uint64_t)kRowsMaxSlots / (kClassicBlock / 64))));
   const int num_slots = std::max((int)grid.x * (kClassicBlock / 64), kBlock / 64);
+  static_assert(kBlock / 64 <= kRowsMaxSlots, "the smallest grid's records fit the scratch array");
+  if (num_slots > kRowsMaxSlots) return fail(GX_ERR_INVALID, "gx_rows_step: %d statistics records exceed the scratch array's %d", num_slots, kRowsMaxSlots);
 
   StatSlot* slots = reinterpret_cast<StatSlot*>(c->scratch);
   StatSlot* result = reinterpret_cast<StatSlot*>(c->scratch + kRowsResultOffset);

@@ -27,8 +27,10 @@ class Context:
         return s.value
 
     def close(self):
+        """gx_ctx_destroy refuses while a batch or communicator of the context is alive; the handle is kept then, so
+        that a later close() can succeed, and the refusal is raised instead of leaking the streams silently"""
         if self._h:
-            L.load().gx_ctx_destroy(self._h)
+            L.check(L.load().gx_ctx_destroy(self._h))
             self._h = C.c_void_p()
 
     def __del__(self):

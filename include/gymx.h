@@ -234,9 +234,10 @@ int gx_vec_get_obs(gx_vec* vec, void* host_obs, size_t bytes);
  * ordered against the compute stream by events. */
 int gx_vec_step_async(gx_vec* vec, const void* h_actions, void* h_obs, void* h_reward, uint8_t* h_done,
                       uint8_t* h_truncated);
-/* Also waits for the stream of the batch's most recent step launch (a caller's own stream
- * included) before it reads the invalid-action flag, so an error is reported by the wait that
- * follows the offending step. */
+/* Also waits for the batch's most recent step launch that can raise the invalid-action flag, on
+ * whichever stream it was enqueued (through an event of the library's own recorded behind it: a
+ * caller's stream handle is never kept, so the caller may destroy its stream once it has
+ * synchronised it), so an error is reported by the wait that follows the offending step. */
 int gx_vec_wait(gx_vec* vec);
 
 /* VectorEnv.Step -- zero-copy path: actions already on the device, results
@@ -285,7 +286,7 @@ int gx_vec_stats(gx_vec* vec, gx_stats* out);
  * by gx_vec_stats, on SoA rows the CALLER owns, for the five classic-control envs in binary32
  * with GX_AUTORESET | GX_RECORD_STATS fused.  It calls no hipMalloc/hipFree or any other
  * allocating routine and only enqueues on `stream`.  The per-wave statistics records its kernels
- * need live in a fixed 2 MiB + 320 B array inside the library, one copy per GPU, held until the
+ * need live in a fixed 2.5 MiB + 320 B array inside the library, one copy per GPU, held until the
  * process ends; that bounds a call at GX_ROWS_MAX_ENVS envs (larger: GX_ERR_INVALID).  Every
  * call on a GPU shares that GPU's array (cleared at the start of each call), so calls that overlap
  * on one GPU -- two streams, two threads -- race: serialise them. */
