@@ -17,12 +17,28 @@ namespace Gymnasium.Gpu;
 public abstract class GpuEnv<TState, TAction, TObs> : Env<TState, TAction>
     where TAction : unmanaged where TObs : unmanaged
 {
-    private readonly Func<GpuVectorEnv<TState, TAction, TObs>> _make;
+    private readonly Func<ulong, ulong, GpuVectorEnv<TState, TAction, TObs>> _make;   // (seed, env index base) -> batch of one
     private GpuVectorEnv<TState, TAction, TObs>? _vec;   // created by the first Reset/Step: constructing an env needs no GPU
     private readonly List<TAction> _one = new() { default };
+    // An env built without a seed takes the next stream of seed 0 (its index keys the counter RNG), so that envs
+    // constructed side by side differ, as the reference's do with their unseeded `new Random()` (Envs.CartPole.cs:19).
+    private ulong _seed = 0;
+    private ulong _stream = Streams.Next();
 
-    protected GpuEnv(Func<GpuVectorEnv<TState, TAction, TObs>> make) { _make = make; }
-    protected GpuVectorEnv<TState, TAction, TObs> Vec => _vec ??= _make();
+    protected GpuEnv(Func<ulong, ulong, GpuVectorEnv<TState, TAction, TObs>> make) { _make = make; }
+    protected GpuVectorEnv<TState, TAction, TObs> Vec => _vec ??= _make(_seed, _stream);
+
+    /// <summary>Extension: the reference's Seed is an empty virtual that no env overrides (Env.cs:33-36).  Here a
+    /// seed re-keys the counter RNG -- stream 0 of that seed, deterministic -- and the batch is rebuilt by the next
+    /// Reset/Step; Seed(null) changes nothing, like the reference's.</summary>
+    public override void Seed(int? seed = null)
+    {
+        if (seed is null) return;
+        _seed = unchecked((ulong)(long)seed.Value);
+        _stream = 0;
+        _vec?.Dispose();
+        _vec = null;
+    }
 
     public override TState Reset() => Vec.Reset()[0];
     public override (TState state, double reward, bool done, IDictionary<string, object> info) Step(TAction action)
@@ -34,8 +50,7 @@ public abstract class GpuEnv<TState, TAction, TObs> : Env<TState, TAction>
     public override void Close() { _vec?.Dispose(); _vec = null; }
 }
 
-// Envs built without a seed take consecutive streams of seed 0, so that envs constructed side by side
-// differ, as the reference's do with their unseeded `new Random()` (Envs.CartPole.cs:19).
+// Consecutive streams of seed 0 for envs built without a seed (see GpuEnv).
 internal static class Streams
 {
     private static long _next = -1;
@@ -46,36 +61,36 @@ public sealed class GpuCartPole : GpuEnv<(float, float, float, float), int, floa
 {
     public Discrete ActionSpace { get; } = new(2);                                      // Envs.CartPole.cs:12
     public Box ObservationSpace { get; } = new(new[] { -2.4f, -3.0f, -0.2095f, -3.0f }, new[] { 2.4f, 3.0f, 0.2095f, 3.0f }); // :13-16
-    public GpuCartPole() : base(() => new(GxEnvId.CartPole, 1, (o, N, i) => (o[i], o[N + i], o[2 * N + i], o[3 * N + i]), envIndexBase: Streams.Next())) { }
+    public GpuCartPole() : base((seed, stream) => new(GxEnvId.CartPole, 1, (o, N, i) => (o[i], o[N + i], o[2 * N + i], o[3 * N + i]), seed: seed, envIndexBase: stream)) { }
 }
 
 public sealed class GpuMountainCar : GpuEnv<(float, float), int, float>
 {
     public Discrete ActionSpace { get; } = new(3);                                      // Envs.MountainCar.cs:12
     public Box ObservationSpace { get; } = new(new[] { -1.2f, -0.07f }, new[] { 0.6f, 0.07f });   // :13-16
-    public GpuMountainCar() : base(() => new(GxEnvId.MountainCar, 1, (o, N, i) => (o[i], o[N + i]), envIndexBase: Streams.Next())) { }
+    public GpuMountainCar() : base((seed, stream) => new(GxEnvId.MountainCar, 1, (o, N, i) => (o[i], o[N + i]), seed: seed, envIndexBase: stream)) { }
 }
 
 public sealed class GpuMountainCarContinuous : GpuEnv<(float, float), float, float>
 {
     public Box ActionSpace { get; } = new(new[] { -1.0f }, new[] { 1.0f });             // Envs.MountainCarContinuous.cs:12
     public Box ObservationSpace { get; } = new(new[] { -1.2f, -0.07f }, new[] { 0.6f, 0.07f });   // :13
-    public GpuMountainCarContinuous() : base(() => new(GxEnvId.MountainCarContinuous, 1, (o, N, i) => (o[i], o[N + i]), envIndexBase: Streams.Next())) { }
+    public GpuMountainCarContinuous() : base((seed, stream) => new(GxEnvId.MountainCarContinuous, 1, (o, N, i) => (o[i], o[N + i]), seed: seed, envIndexBase: stream)) { }
 }
 
 public sealed class GpuPendulum : GpuEnv<float[], float, float>
 {
     public Box ActionSpace { get; } = new(new[] { -2.0f }, new[] { 2.0f });             // Envs.Pendulum.cs:12
     public Box ObservationSpace { get; } = new(new[] { -1.0f, -1.0f, -8.0f }, new[] { 1.0f, 1.0f, 8.0f }); // :13
-    public GpuPendulum() : base(() => new(GxEnvId.Pendulum, 1, (o, N, i) => new[] { o[i], o[N + i], o[2 * N + i] }, envIndexBase: Streams.Next())) { }
+    public GpuPendulum() : base((seed, stream) => new(GxEnvId.Pendulum, 1, (o, N, i) => new[] { o[i], o[N + i], o[2 * N + i] }, seed: seed, envIndexBase: stream)) { }
 }
 
 public sealed class GpuAcrobot : GpuEnv<float[], int, float>
 {
     public Discrete ActionSpace { get; } = new(3);                                      // Envs.Acrobot.cs:12
     public Box ObservationSpace { get; } = new(new[] { -1f, -1f, -1f, -1f, -6f, -6f }, new[] { 1f, 1f, 1f, 1f, 6f, 6f }); // :13-16
-    public GpuAcrobot() : base(() => new(GxEnvId.Acrobot, 1,
-        (o, N, i) => new[] { o[i], o[N + i], o[2 * N + i], o[3 * N + i], o[4 * N + i], o[5 * N + i] }, envIndexBase: Streams.Next())) { }
+    public GpuAcrobot() : base((seed, stream) => new(GxEnvId.Acrobot, 1,
+        (o, N, i) => new[] { o[i], o[N + i], o[2 * N + i], o[3 * N + i], o[4 * N + i], o[5 * N + i] }, seed: seed, envIndexBase: stream)) { }
     // torque[action] throws IndexOutOfRangeException (Envs.Acrobot.cs:45,51); the library reports GX_ERR_INVALID
     public override (float[] state, double reward, bool done, IDictionary<string, object> info) Step(int action)
     {
@@ -89,9 +104,29 @@ public sealed class GpuFrozenLake : GpuEnv<int, int, int>
     public Discrete ActionSpace { get; } = new(4);                                      // Envs.FrozenLake.cs:12
     public Discrete ObservationSpace { get; }                                           // :33
     public GpuFrozenLake(string[]? map = null)                                          // the constructor argument of :23
-        : base(() => new(GxEnvId.FrozenLake, 1, (o, N, i) => o[i], envIndexBase: Streams.Next(), mapRows: map is null ? null : string.Join('/', map)))
+        : base((seed, stream) => new(GxEnvId.FrozenLake, 1, (o, N, i) => o[i], seed: seed, envIndexBase: stream, mapRows: map is null ? null : string.Join('/', map)))
     {
         ObservationSpace = new(map is null ? 16 : map.Length * map[0].Length);
+    }
+}
+
+/// <summary>Env&lt;int,int&gt; stepped from a transition table the caller supplies (gx_desc.table): what FrozenLake's
+/// `map` argument (Envs.FrozenLake.cs:23) generalises to.  An action outside Discrete(NActions) throws
+/// IndexOutOfRangeException, as an out-of-range index does in the reference.</summary>
+public sealed class GpuTableEnv : GpuEnv<int, int, int>
+{
+    public Discrete ActionSpace { get; }
+    public Discrete ObservationSpace { get; }
+    public GpuTableEnv(GxTable table)
+        : base((seed, stream) => new(GxEnvId.Table, 1, (o, N, i) => o[i], seed: seed, envIndexBase: stream, table: table))
+    {
+        ActionSpace = new(table.NActions);
+        ObservationSpace = new(table.NStates);
+    }
+    public override (int state, double reward, bool done, IDictionary<string, object> info) Step(int action)
+    {
+        try { return base.Step(action); }
+        catch (ArgumentException e) { throw new IndexOutOfRangeException(e.Message); }
     }
 }
 
@@ -99,14 +134,14 @@ public sealed class GpuTaxi : GpuEnv<int, int, int>
 {
     public Discrete ActionSpace { get; } = new(6);                                      // Envs.Taxi.cs:12
     public Discrete ObservationSpace { get; } = new(500);                               // :13
-    public GpuTaxi() : base(() => new(GxEnvId.Taxi, 1, (o, N, i) => o[i], envIndexBase: Streams.Next())) { }
+    public GpuTaxi() : base((seed, stream) => new(GxEnvId.Taxi, 1, (o, N, i) => o[i], seed: seed, envIndexBase: stream)) { }
 }
 
 public sealed class GpuCliffWalking : GpuEnv<int, int, int>
 {
     public Discrete ActionSpace { get; } = new(4);                                      // Envs.CliffWalking.cs:12
     public Discrete ObservationSpace { get; } = new(48);                                // :13
-    public GpuCliffWalking() : base(() => new(GxEnvId.CliffWalking, 1, (o, N, i) => o[i], envIndexBase: Streams.Next())) { }
+    public GpuCliffWalking() : base((seed, stream) => new(GxEnvId.CliffWalking, 1, (o, N, i) => o[i], seed: seed, envIndexBase: stream)) { }
 }
 
 public sealed class GpuBlackjack : GpuEnv<(int, int, bool), int, int>
@@ -115,8 +150,8 @@ public sealed class GpuBlackjack : GpuEnv<(int, int, bool), int, int>
     public Discrete ObservationSpace { get; } = new(32 * 11 * 2);                       // :13
     /// <param name="upstreamRules">false: the reference's ten-step stub (Envs.Blackjack.cs:34-39); true: upstream Blackjack-v1</param>
     public GpuBlackjack(bool upstreamRules = false)
-        : base(() => new(GxEnvId.Blackjack, 1, (o, N, i) => (o[i] / 22, (o[i] / 2) % 11, (o[i] & 1) != 0),
-                         flags: upstreamRules ? GxFlags.BlackjackFull : GxFlags.None, envIndexBase: Streams.Next())) { }
+        : base((seed, stream) => new(GxEnvId.Blackjack, 1, (o, N, i) => (o[i] / 22, (o[i] / 2) % 11, (o[i] & 1) != 0),
+                         flags: upstreamRules ? GxFlags.BlackjackFull : GxFlags.None, seed: seed, envIndexBase: stream)) { }
 }
 
 /// <summary>The three frame games: byte[] states of 210*160*3, info dictionaries as the reference fills them.</summary>
@@ -127,7 +162,7 @@ public abstract class GpuFrameEnv : GpuEnv<byte[], int, byte>
                                                Enumerable.Repeat(255.0f, GpuEnvs.FrameBytes).ToArray());
     public override object? Metadata => new { render_modes = new[] { "human", "rgb_array" } };                  // Envs.Pong.cs:44
     protected GpuFrameEnv(GxEnvId id, int actions)
-        : base(() => new(id, 1, (o, N, i) => o.AsSpan(i * GpuEnvs.FrameBytes, GpuEnvs.FrameBytes).ToArray(), envIndexBase: Streams.Next()))
+        : base((seed, stream) => new(id, 1, (o, N, i) => o.AsSpan(i * GpuEnvs.FrameBytes, GpuEnvs.FrameBytes).ToArray(), seed: seed, envIndexBase: stream))
     {
         ActionSpace = new(actions);
     }

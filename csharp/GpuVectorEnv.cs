@@ -39,19 +39,26 @@ public sealed unsafe class GpuVectorEnv<TState, TAction, TObs> : IDisposable
 
     public GpuVectorEnv(GxEnvId env, int numEnvs, StateReader<TObs, TState> stateOf, ulong seed = 0,
                         GxFlags flags = GxFlags.None, int timeLimit = 0, GxMode mode = GxMode.Exact,
-                        int device = 0, ulong envIndexBase = 0, string? mapRows = null)
+                        int device = 0, ulong envIndexBase = 0, string? mapRows = null, GxTable? table = null)
     {
         _ctx = ContextHandle.Create(device);
         _stateOf = stateOf;
         _timeLimit = timeLimit;
         byte[]? map = mapRows is null ? null : System.Text.Encoding.UTF8.GetBytes(mapRows + "\0");
         fixed (byte* pMap = map)
+        fixed (GxTransition* pTable = table?.Entries)   // copied by gx_vec_create; not kept
         {
             var d = new GxDesc
             {
                 StructSize = (uint)sizeof(GxDesc), EnvId = (int)env, NumEnvs = (ulong)numEnvs, Seed = seed,
                 EnvIndexBase = envIndexBase, Mode = (int)mode, Flags = (uint)flags, TimeLimit = timeLimit, MapRows = pMap,
             };
+            if (table is not null)
+            {
+                d.Table = pTable; d.TableLen = (ulong)table.Entries.Length;
+                d.NStates = table.NStates; d.NActions = table.NActions; d.NOutcomes = table.NOutcomes;
+                d.StartState = table.StartState; d.StepLimit = table.StepLimit;
+            }
             Native.Check(Native.gx_vec_create(_ctx.DangerousGetHandle(), &d, out IntPtr v));
             _vec.Set(v, _ctx);
         }
@@ -245,6 +252,9 @@ public static class GpuEnvs
         => new(GxEnvId.Taxi, n, (o, N, i) => o[i], seed, flags, timeLimit);
     public static GpuVectorEnv<int, int, int> CliffWalking(int n, ulong seed = 0, GxFlags flags = GxFlags.None, int timeLimit = 0)
         => new(GxEnvId.CliffWalking, n, (o, N, i) => o[i], seed, flags, timeLimit);
+    // a table-driven env whose transitions the caller supplies (what FrozenLake's map argument generalises to)
+    public static GpuVectorEnv<int, int, int> Table(int n, GxTable table, ulong seed = 0, GxFlags flags = GxFlags.None, int timeLimit = 0)
+        => new(GxEnvId.Table, n, (o, N, i) => o[i], seed, flags, timeLimit, table: table);
     // Envs.Blackjack.cs:10: (playerSum, dealerCard, usableAce); the device holds the index of Discrete(32*11*2)
     public static GpuVectorEnv<(int, int, bool), int, int> Blackjack(int n, ulong seed = 0, GxFlags flags = GxFlags.None, int timeLimit = 0)
         => new(GxEnvId.Blackjack, n, (o, N, i) => (o[i] / 22, (o[i] / 2) % 11, (o[i] & 1) != 0), seed, flags, timeLimit);

@@ -14,7 +14,8 @@ public enum GxStatus { Ok = 0, Invalid = 1, Hip = 2, Oom = 3, Unsupported = 4, R
 public enum GxEnvId
 {
     CartPole = 0, MountainCar = 1, MountainCarContinuous = 2, Pendulum = 3, Acrobot = 4,
-    FrozenLake = 5, Taxi = 6, CliffWalking = 7, Pong = 8, Dummy = 9, Breakout = 10, SpaceInvaders = 11, Blackjack = 12
+    FrozenLake = 5, Taxi = 6, CliffWalking = 7, Pong = 8, Dummy = 9, Breakout = 10, SpaceInvaders = 11, Blackjack = 12,
+    Table = 13
 }
 
 public enum GxMode { Exact = 0, Fast32 = 1, Fp64 = 2 }
@@ -41,6 +42,29 @@ public unsafe struct GxDesc
     public int TimeLimit;
     public int Reserved;
     public byte* MapRows; // UTF-8, rows joined by '/', or null
+    // GxEnvId.Table only
+    public GxTransition* Table; // [NStates][NActions][NOutcomes]
+    public ulong TableLen;
+    public int NStates, NActions, NOutcomes, StartState, StepLimit, Reserved2;
+}
+
+// gx_transition: one entry of a caller-supplied table
+[StructLayout(LayoutKind.Sequential)]
+public struct GxTransition
+{
+    public int NextState;
+    public float Reward;
+    public int Done;
+}
+
+/// <summary>A caller-supplied transition table for GxEnvId.Table: Entries[(s * NActions + a) * NOutcomes + o].</summary>
+public sealed class GxTable
+{
+    public GxTransition[] Entries = Array.Empty<GxTransition>();
+    public int NStates, NActions;
+    public int NOutcomes = 1;   // 1, or 3 equally likely outcomes drawn per step
+    public int StartState = 0;  // Reset(): this state; -1: a uniform draw over the states (Envs.Taxi.cs:20)
+    public int StepLimit = 0;   // the env's own `steps >= limit` term of done (Envs.FrozenLake.cs:65); 0: none
 }
 
 [StructLayout(LayoutKind.Sequential)]

@@ -4,12 +4,12 @@ from . import spaces
 from .env import (ActionWrapper, Env, EnvWrapper, ObservationWrapper, RecordEpisodeStatistics, RewardWrapper,
                   TimeLimit)
 from .envs import (Acrobot, Blackjack, Breakout, CartPole, CliffWalking, DummyEnv, FrozenLake, MountainCar,
-                   MountainCarContinuous, Pendulum, Pong, SpaceInvaders, Taxi)
+                   MountainCarContinuous, Pendulum, Pong, SpaceInvaders, TableEnv, Taxi)
 from .registry import EnvRegistry, RegisterAll
 from .spaces import Box, Dict, Discrete, MultiBinary, MultiDiscrete, Tuple
 from .vector_env import VectorEnv
 
 __all__ = ["spaces", "Env", "EnvWrapper", "ObservationWrapper", "ActionWrapper", "RewardWrapper",
            "RecordEpisodeStatistics", "TimeLimit", "CartPole", "MountainCar", "MountainCarContinuous", "Pendulum",
-           "Acrobot", "FrozenLake", "Taxi", "CliffWalking", "Blackjack", "Pong", "Breakout", "SpaceInvaders", "DummyEnv", "EnvRegistry", "RegisterAll",
+           "Acrobot", "FrozenLake", "Taxi", "TableEnv", "CliffWalking", "Blackjack", "Pong", "Breakout", "SpaceInvaders", "DummyEnv", "EnvRegistry", "RegisterAll",
            "Box", "Discrete", "MultiBinary", "MultiDiscrete", "Tuple", "Dict", "VectorEnv"]

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("GYMX_LIB") or os.path.join(_HERE, "lib", "libgymx.so"
 GX_OK, GX_ERR_INVALID, GX_ERR_HIP, GX_ERR_OOM, GX_ERR_UNSUPPORTED, GX_ERR_RCCL = range(6)
 
 (ENV_CARTPOLE, ENV_MOUNTAINCAR, ENV_MOUNTAINCAR_CONT, ENV_PENDULUM, ENV_ACROBOT, ENV_FROZENLAKE, ENV_TAXI,
- ENV_CLIFFWALKING, ENV_PONG, ENV_DUMMY, ENV_BREAKOUT, ENV_SPACEINVADERS, ENV_BLACKJACK) = range(13)
+ ENV_CLIFFWALKING, ENV_PONG, ENV_DUMMY, ENV_BREAKOUT, ENV_SPACEINVADERS, ENV_BLACKJACK, ENV_TABLE) = range(14)
 MODE_EXACT, MODE_FAST32, MODE_FP64 = 0, 1, 2
 AUTORESET, RECORD_STATS, SLIPPERY, TAXI_FULL, ACROBOT_RK4, BLACKJACK_FULL = 1, 2, 4, 8, 16, 64
 POLICY_DEVICE_ACTIONS, POLICY_RANDOM = 0, 1
@@ -26,7 +26,18 @@ class GxDesc(C.Structure):
         ("struct_size", C.c_uint32), ("env_id", C.c_int32), ("num_envs", C.c_uint64), ("seed", C.c_uint64),
         ("env_index_base", C.c_uint64), ("mode", C.c_int32), ("flags", C.c_uint32), ("time_limit", C.c_int32),
         ("reserved", C.c_int32), ("map_rows", C.c_char_p),
+        # GX_ENV_TABLE only
+        ("table", C.c_void_p), ("table_len", C.c_uint64), ("n_states", C.c_int32), ("n_actions", C.c_int32),
+        ("n_outcomes", C.c_int32), ("start_state", C.c_int32), ("step_limit", C.c_int32), ("reserved2", C.c_int32),
     ]
+
+
+class GxTransition(C.Structure):
+    """gx_transition: one entry of a caller-supplied table"""
+    _fields_ = [("next_state", C.c_int32), ("reward", C.c_float), ("done", C.c_int32)]
+
+
+DESC_SIZE_V1 = 56  # GX_DESC_SIZE_V1: the struct before the GX_ENV_TABLE fields
 
 
 class GxInfo(C.Structure):

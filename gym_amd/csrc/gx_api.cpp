@@ -12,6 +12,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <cstddef>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -120,6 +121,8 @@ struct gx_vec {
   int ret_per_step = 0;
   // tabular
   int table_states = 0, table_actions = 0, table_outcomes = 1, start_state = 0, step_limit = 0;
+  int table_lut = 8;  // reward values behind the packed entries
+  std::vector<gx_transition> user_table;  // GX_ENV_TABLE: the caller's entries until they are compiled (gx_vec_create)
   size_t table_lds_bytes = 0;
   dim3 grid;
   unsigned grid_single = 0;  // workgroups of a single step where that differs from `grid` (large classic-control batches); 0: the same
@@ -319,9 +322,57 @@ void taxi_full(int s, int a, int& ns, int& ridx, bool& term) {
   ns = ((row * 5 + col) * 5 + pass) * 4 + dest;
 }
 
+// GX_ENV_TABLE: the caller's P[s][a][o] -> (next state, reward, done), checked and packed like the built-in envs'
+// tables.  Column A, the built-in envs' "any other action" case, repeats action 0: an action outside the space is an
+// error here (the host path rejects it, the zero-copy path raises the batch's error flag).
+int build_user_table(gx_vec* v, std::vector<uint32_t>& tab, std::vector<float>& lut) {
+  const gx_desc& d = v->desc;
+  const int S = d.n_states, A = d.n_actions, O = d.n_outcomes == 0 ? 1 : d.n_outcomes;
+  if (v->user_table.empty()) return fail(GX_ERR_INVALID, "gx_vec_create: GX_ENV_TABLE needs gx_desc.table");
+  if (S < 1 || S > 65536) return fail(GX_ERR_INVALID, "gx_vec_create: n_states %d outside 1..65536", S);
+  if (A < 1 || A > 255) return fail(GX_ERR_INVALID, "gx_vec_create: n_actions %d outside 1..255", A);
+  if (O != 1 && O != 3) return fail(GX_ERR_UNSUPPORTED, "gx_vec_create: n_outcomes %d (1, or 3 equally likely outcomes)", O);
+  if (v->user_table.size() != (size_t)S * A * O)
+    return fail(GX_ERR_INVALID, "gx_vec_create: table_len %zu, expected n_states * n_actions * n_outcomes = %zu", v->user_table.size(), (size_t)S * A * O);
+  if (d.start_state < -1 || d.start_state >= S) return fail(GX_ERR_INVALID, "gx_vec_create: start_state %d outside -1..%d", d.start_state, S - 1);
+  if (d.step_limit < 0) return fail(GX_ERR_INVALID, "gx_vec_create: negative step_limit");
+  const bool stats = (d.flags & GX_RECORD_STATS) != 0;
+  lut.clear();
+  tab.assign((size_t)S * (A + 1) * O, 0);
+  for (int s = 0; s < S; s++)
+    for (int col = 0; col <= A; col++)
+      for (int o = 0; o < O; o++) {
+        const int a = col < A ? col : 0;
+        const size_t at = ((size_t)s * A + a) * O + o;
+        const gx_transition& t = v->user_table[at];
+        if (t.next_state < 0 || t.next_state >= S)
+          return fail(GX_ERR_INVALID, "gx_vec_create: table entry %zu (state %d, action %d, outcome %d) leads to state %d outside 0..%d", at, s, a, o, t.next_state, S - 1);
+        if (!std::isfinite(t.reward)) return fail(GX_ERR_INVALID, "gx_vec_create: table entry %zu has a reward that is not finite", at);
+        if (stats && (t.reward != std::nearbyint(t.reward) || std::fabs(t.reward) > 1048576.0f))
+          return fail(GX_ERR_UNSUPPORTED, "gx_vec_create: table entry %zu pays %g; with GX_RECORD_STATS rewards must be integers of magnitude at most 2^20", at, (double)t.reward);
+        size_t ridx = 0;
+        while (ridx < lut.size() && std::memcmp(&lut[ridx], &t.reward, sizeof(float)) != 0) ridx++;  // by bits: -0.0f and 0.0f stay apart
+        if (ridx == lut.size()) {
+          if (lut.size() == 256) return fail(GX_ERR_UNSUPPORTED, "gx_vec_create: the table pays more than 256 distinct rewards");
+          lut.push_back(t.reward);
+        }
+        tab[((size_t)s * (A + 1) + col) * O + o] = (uint32_t)t.next_state | ((uint32_t)ridx << 16) | (t.done ? kTerminalBit : 0u);
+      }
+  lut.resize(std::max<size_t>(8, (lut.size() + 3) & ~(size_t)3), 0.0f);
+  v->table_states = S; v->table_actions = A; v->table_outcomes = O;
+  v->start_state = d.start_state;
+  v->step_limit = d.step_limit > 0 ? d.step_limit : std::numeric_limits<int32_t>::max();
+  return GX_OK;
+}
+
 int build_table(gx_vec* v, std::vector<uint32_t>& tab) {
   const int env = v->desc.env_id;
   float lut[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  std::vector<float> user_lut;
+  if (env == GX_ENV_TABLE) {
+    int rc = build_user_table(v, tab, user_lut);
+    if (rc != GX_OK) return rc;
+  } else
   if (env == GX_ENV_FROZENLAKE || env == GX_ENV_CLIFFWALKING) {
     Grid g;
     const bool cliff = env == GX_ENV_CLIFFWALKING;
@@ -372,15 +423,24 @@ int build_table(gx_vec* v, std::vector<uint32_t>& tab) {
   } else {
     return GX_OK;
   }
-  std::memcpy(&tab[tab.size() - 8], lut, sizeof lut);
+  const float* rewards = lut;
+  if (env == GX_ENV_TABLE) {
+    const size_t entries = tab.size();
+    tab.resize(entries + user_lut.size());
+    std::memcpy(&tab[entries], user_lut.data(), user_lut.size() * sizeof(float));
+    v->table_lut = (int)user_lut.size();
+    rewards = user_lut.data();
+  } else {
+    std::memcpy(&tab[tab.size() - 8], lut, sizeof lut);
+  }
   // Does every non-terminal transition pay the same integer reward?  Then, with auto-reset on,
   // the open-episode return is that reward times the step counter (see derive_returns).
   {
     bool constant = true, seen = false;
     float c = 0.0f;
-    for (size_t i = 0; i + 8 < tab.size(); i++) {
+    for (size_t i = 0; i + (size_t)v->table_lut < tab.size(); i++) {
       if (tab[i] & kTerminalBit) continue;
-      const float r = lut[(tab[i] >> 16) & 0x7u];
+      const float r = rewards[(tab[i] >> 16) & 0xFFu];
       if (!seen) { c = r; seen = true; }
       else if (r != c) constant = false;
     }
@@ -437,6 +497,7 @@ void fill_info(gx_vec* v) {
       in.action_n = 6; in.obs_is_state = 0;
       break;
     case GX_ENV_BLACKJACK: in.n_real = 0; in.n_int = 3; in.obs_dim = 1; in.obs_dtype = GX_I32; in.action_n = 2; break;  // Envs.Blackjack.cs:12-13
+    case GX_ENV_TABLE: in.n_real = 0; in.n_int = 2; in.obs_dim = 1; in.obs_dtype = GX_I32; in.action_n = v->desc.n_actions; break;
   }
   if (v->is_classic64) in.real_dtype = in.obs_dtype = GX_F64;  // the observation is the binary64 state image
   in.state_bytes = v->n * ((uint64_t)in.n_real * dtype_size(in.real_dtype) + (uint64_t)in.n_int * 4);
@@ -503,6 +564,8 @@ StepArgs make_args(const gx_vec* v, const void* d_actions, int k_steps, uint64_t
   a.table_states = v->table_states;
   a.table_actions = v->table_actions;
   a.table_outcomes = v->table_outcomes;
+  a.table_lut = v->table_lut;
+  a.strict_actions = v->desc.env_id == GX_ENV_TABLE ? 1 : 0;
   a.start_state = v->start_state;
   a.step_limit = v->step_limit;
   a.derive_returns = v->derive_returns ? 1 : 0;
@@ -513,7 +576,8 @@ StepArgs make_args(const gx_vec* v, const void* d_actions, int k_steps, uint64_t
 
 // Only Acrobot has actions the reference throws on (Envs.Acrobot.cs:45,51); the host path
 // validates them before launch, so the device flag matters for the zero-copy path alone.
-bool has_error_flag(const gx_vec* v) { return v->desc.env_id == GX_ENV_ACROBOT; }
+// A caller-supplied table has no column for an action outside its space and treats one the same way.
+bool has_error_flag(const gx_vec* v) { return v->desc.env_id == GX_ENV_ACROBOT || v->desc.env_id == GX_ENV_TABLE; }
 
 // waits for the most recent launch on a caller's stream that the library has to order itself after
 int wait_foreign(gx_vec* v) {
@@ -621,9 +685,14 @@ extern "C" int gx_vec_destroy(gx_vec* v) {
 extern "C" int gx_vec_create(gx_ctx* ctx, const gx_desc* desc, gx_vec** out) {
   if (!ctx || !desc || !out) return fail(GX_ERR_INVALID, "gx_vec_create: null argument");
   *out = nullptr;
-  if (desc->struct_size != sizeof(gx_desc))
-    return fail(GX_ERR_INVALID, "gx_vec_create: gx_desc.struct_size is %u, expected %zu", desc->struct_size, sizeof(gx_desc));
+  static_assert(offsetof(gx_desc, table) == GX_DESC_SIZE_V1, "the fields before gx_desc.table are the first version of the struct");
+  if (desc->struct_size != sizeof(gx_desc) && desc->struct_size != GX_DESC_SIZE_V1)
+    return fail(GX_ERR_INVALID, "gx_vec_create: gx_desc.struct_size is %u, expected %zu (or %u, without the GX_ENV_TABLE fields)", desc->struct_size, sizeof(gx_desc), GX_DESC_SIZE_V1);
   if (desc->env_id < 0 || desc->env_id >= GX_ENV_COUNT) return fail(GX_ERR_INVALID, "gx_vec_create: unknown env id %d", desc->env_id);
+  if (desc->env_id == GX_ENV_TABLE && desc->struct_size != sizeof(gx_desc))
+    return fail(GX_ERR_INVALID, "gx_vec_create: GX_ENV_TABLE needs the whole gx_desc (struct_size %zu)", sizeof(gx_desc));
+  if (desc->env_id == GX_ENV_TABLE && (!desc->table || desc->table_len == 0 || desc->table_len > (1ull << 26)))
+    return fail(GX_ERR_INVALID, "gx_vec_create: GX_ENV_TABLE needs gx_desc.table with 1..2^26 entries");
   if (desc->num_envs == 0) return fail(GX_ERR_INVALID, "gx_vec_create: num_envs must be positive");
   if (desc->num_envs > (1ull << 31)) return fail(GX_ERR_UNSUPPORTED, "gx_vec_create: more than 2^31 envs per batch");
   if (desc->mode != GX_MODE_EXACT && desc->mode != GX_MODE_FAST32 && desc->mode != GX_MODE_FP64) return fail(GX_ERR_INVALID, "gx_vec_create: unknown mode %d", desc->mode);
@@ -636,9 +705,12 @@ extern "C" int gx_vec_create(gx_ctx* ctx, const gx_desc* desc, gx_vec** out) {
   if (!v) return fail(GX_ERR_OOM, "gx_vec_create: host allocation failed");
   v->ctx = ctx;
   ctx->live_handles++;
-  v->desc = *desc;
+  std::memcpy(&v->desc, desc, desc->struct_size);  // a first-version struct leaves the table fields zero
+  v->desc.struct_size = sizeof(gx_desc);
   if (desc->map_rows) v->map = desc->map_rows;
   v->desc.map_rows = nullptr;
+  if (desc->env_id == GX_ENV_TABLE) v->user_table.assign(desc->table, desc->table + desc->table_len);
+  v->desc.table = nullptr;  // the caller's array is not kept
   v->n = desc->num_envs;
   const int env = desc->env_id;
   v->is_acrobot64 = env == GX_ENV_ACROBOT && (desc->flags & GX_ACROBOT_RK4);
@@ -650,7 +722,7 @@ extern "C" int gx_vec_create(gx_ctx* ctx, const gx_desc* desc, gx_vec** out) {
   }
   v->classic_id = v->acrobot_angles ? kEnvAcrobotAngles : env;
   v->is_blackjack = env == GX_ENV_BLACKJACK;
-  v->is_tabular = env == GX_ENV_FROZENLAKE || env == GX_ENV_TAXI || env == GX_ENV_CLIFFWALKING || env == GX_ENV_DUMMY || v->is_blackjack;
+  v->is_tabular = env == GX_ENV_FROZENLAKE || env == GX_ENV_TAXI || env == GX_ENV_CLIFFWALKING || env == GX_ENV_DUMMY || v->is_blackjack || env == GX_ENV_TABLE;
   v->is_frame = env == GX_ENV_PONG || env == GX_ENV_BREAKOUT || env == GX_ENV_SPACEINVADERS;
   v->envs_per_lane = (v->is_acrobot64 || v->is_classic64) ? 2 : (v->is_frame ? 1 : 4);
   v->stride = (v->n + 3) & ~3ull;  // rows stay 16-byte aligned for every element width
@@ -685,6 +757,8 @@ extern "C" int gx_vec_create(gx_ctx* ctx, const gx_desc* desc, gx_vec** out) {
   if (v->is_tabular && env != GX_ENV_DUMMY && !v->is_blackjack) {
     int rc = build_table(v, table);
     if (rc != GX_OK) { gx_vec_destroy(v); return rc; }
+    v->user_table.clear();
+    v->user_table.shrink_to_fit();
     table.resize((table.size() + 3) & ~(size_t)3, 0);  // the kernels stage it in 16-byte pieces
     VEC_TRY(hipMalloc((void**)&v->d_table, table.size() * 4));
     VEC_TRY(hipMemcpy(v->d_table, table.data(), table.size() * 4, hipMemcpyHostToDevice));
@@ -1034,6 +1108,16 @@ extern "C" int gx_vec_step_async(gx_vec* v, const void* h_actions, void* h_obs, 
     if (bad)
       for (uint64_t i = 0; i < v->n; i++)
         if ((uint32_t)act[i] > 2u) return fail(GX_ERR_INVALID, "Acrobot: action %d of env %llu is outside {0,1,2}", act[i], (unsigned long long)i);
+  }
+  if (v->desc.env_id == GX_ENV_TABLE) {
+    // an action outside a caller-supplied table's space has no transition: rejected like Acrobot's
+    const int32_t* act = static_cast<const int32_t*>(h_actions);
+    const uint32_t na = (uint32_t)v->table_actions;
+    uint32_t bad = 0;
+    for (uint64_t i = 0; i < v->n; i++) bad |= (uint32_t)((uint32_t)act[i] >= na);
+    if (bad)
+      for (uint64_t i = 0; i < v->n; i++)
+        if ((uint32_t)act[i] >= na) return fail(GX_ERR_INVALID, "table env: action %d of env %llu is outside Discrete(%u)", act[i], (unsigned long long)i, na);
   }
   if (v->h_stage) {
     if (v->stage_pending) {  // a step that was never waited for: its results go to its buffers first

@@ -300,6 +300,8 @@ struct StepArgs {
   int32_t skip_last;       // GX_OUT_NONE: the reward / done / truncated rows of the view are not written
   uint32_t reverse;        // sweep the batch back to front (alternates launch to launch)
   int32_t table_states, table_actions, table_outcomes;
+  int32_t table_lut;       // reward values that follow the packed entries (a multiple of 4, at least 8)
+  uint32_t strict_actions; // tabular: an action outside the space raises error_flag (caller-supplied tables)
   int32_t start_state;
   int32_t step_limit;
   // 1: the open-episode return is not stored; it is ret_per_step x the step counter (envs whose

@@ -3,7 +3,8 @@
 // The host compiles an env into a packed transition table
 //   entry[(state * (A + 1) + column) * O + outcome]
 //     bits  0..15  next state
-//     bits 16..23  index into the reward table that follows the entries
+//     bits 16..23  index into the reward table that follows the entries (a.table_lut values: eight for the
+//                  built-in envs, up to 256 for a caller-supplied table)
 //     bit  24      terminal (goal / hole / cliff / delivered)
 // with A the size of the Discrete action space, column A the "any other
 // action" case (Envs.FrozenLake.cs:56-62: a switch without default leaves the
@@ -45,11 +46,11 @@ __device__ __forceinline__ void store_step_rows(const StepArgs& a, int k, uint64
 }
 
 // Reset state: FrozenLake 0 (Envs.FrozenLake.cs:47), CliffWalking 36
-// (Envs.CliffWalking.cs:31), Taxi `Next(500)` (Envs.Taxi.cs:20).
-__device__ __forceinline__ int32_t tabular_reset_state(int32_t start_state, const RngKey& key, uint64_t env) {
+// (Envs.CliffWalking.cs:31), Taxi `Next(500)` (Envs.Taxi.cs:20: -1, a uniform draw over the table's states).
+__device__ __forceinline__ int32_t tabular_reset_state(int32_t start_state, int32_t n_states, const RngKey& key, uint64_t env) {
   if (start_state >= 0) return start_state;
   Draws d = philox_block(key, env, 0, 0);
-  if (start_state == -1) return d.below(0, 500);
+  if (start_state == -1) return d.below(0, n_states);
   // extension (upstream Taxi-v3): passenger neither in the taxi nor at the destination
   int k = d.below(0, 300);
   int cell = k / 12, rem = k % 12, pass = rem / 3, d3 = rem % 3;
@@ -74,12 +75,12 @@ __global__ void __launch_bounds__(kTabularBlock) tabular_step_kernel(StepArgs a)
       // sixteen bytes per lane and trip (the device copy of the table is padded to a multiple of four words): at
       // 64 Mi envs the Taxi stub steps in 0.283 instead of 0.303 ms, full Taxi-v3 in 0.402 instead of 0.413, the
       // 8x8 FrozenLake in 0.278 instead of 0.285
-      const int chunks = (entries + 8 + 3) >> 2;
+      const int chunks = (entries + a.table_lut + 3) >> 2;
       for (int i = threadIdx.x; i < chunks; i += blockDim.x)
         reinterpret_cast<uint4*>(lds_table)[i] = reinterpret_cast<const uint4*>(a.table)[i];
     } else {
       // with the actions sampled in the kernel the word-by-word copy is the faster one by 1-1.5 % (same runs)
-      for (int i = threadIdx.x; i < entries + 8; i += blockDim.x) lds_table[i] = a.table[i];
+      for (int i = threadIdx.x; i < entries + a.table_lut; i += blockDim.x) lds_table[i] = a.table[i];
     }
     __syncthreads();
     tab = lds_table;
@@ -94,6 +95,7 @@ __global__ void __launch_bounds__(kTabularBlock) tabular_step_kernel(StepArgs a)
   int32_t* const state_row = a.state_int;
   int32_t* const steps_row = a.state_int + a.stride;
   ThreadStats<int32_t> acc;  // every reward of a table is an integer: branch-free integer accumulation
+  uint32_t bad_action = 0;   // device actions only: one outside the space (an error for caller-supplied tables)
 
   const uint64_t nquads = (a.num_envs + 3) >> 2;
   for (uint64_t it = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; it < nquads; it += (uint64_t)gridDim.x * blockDim.x) {
@@ -139,12 +141,13 @@ __global__ void __launch_bounds__(kTabularBlock) tabular_step_kernel(StepArgs a)
         const uint32_t w = word[j];
         if (POLICY == GX_POLICY_RANDOM) act[j] = word_below(w, A);
         const int col = (uint32_t)act[j] < (uint32_t)A ? act[j] : A;
+        if (POLICY == GX_POLICY_DEVICE_ACTIONS) bad_action |= (uint32_t)(col == A && q * 4 + j < a.num_envs);
         const int o = (SLIP && col < A) ? word_outcome(w, A, O) : 0;
         // a state outside the table (only reachable through set_state) is clamped
         const int s_in = (uint32_t)st[j] < (uint32_t)a.table_states ? st[j] : 0;
         const uint32_t e = tab[(s_in * ncols + col) * O + o];
         st[j] = (int32_t)(e & 0xFFFFu);
-        reward[j] = lut[(e >> 16) & 0x7u];
+        reward[j] = lut[(e >> 16) & 0xFFu];
         steps[j] += 1;
         bool d = ((e >> 24) & 1u) != 0 || steps[j] >= a.step_limit;
         bool t = a.time_limit > 0 && steps[j] >= a.time_limit;  // Wrappers.TimeLimit.cs:26-31
@@ -159,7 +162,7 @@ __global__ void __launch_bounds__(kTabularBlock) tabular_step_kernel(StepArgs a)
           ep_len[j] = d ? 0 : ep_len[j];
         }
         if (autoreset && d) {
-          st[j] = tabular_reset_state(a.start_state, key, env);
+          st[j] = tabular_reset_state(a.start_state, a.table_states, key, env);
           steps[j] = 0;
         }
       }
@@ -179,6 +182,7 @@ __global__ void __launch_bounds__(kTabularBlock) tabular_step_kernel(StepArgs a)
     }
   }
   if (record) block_commit_stats(acc.widen(), a.stat_slots);
+  if (POLICY == GX_POLICY_DEVICE_ACTIONS && a.strict_actions && bad_action) atomicOr(a.error_flag, 1u);
 }
 
 // DummyEnv.cs:23-30: state += action; reward = state; done = state >= 10.
@@ -257,7 +261,7 @@ __global__ void __launch_bounds__(kTabularBlock) tabular_reset_kernel(StepArgs a
   for (uint64_t q = (uint64_t)blockIdx.x * kTabularBlock + threadIdx.x; q < nquads; q += (uint64_t)gridDim.x * kTabularBlock) {
     int32_t st[4], zero[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int j = 0; j < 4; j++) st[j] = tabular_reset_state(a.start_state, key, a.env_index_base + q * 4 + j);
+    for (int j = 0; j < 4; j++) st[j] = tabular_reset_state(a.start_state, a.table_states, key, a.env_index_base + q * 4 + j);
     store4i(a.state_int, q, st);
     store4i(a.state_int + a.stride, q, zero);
   }

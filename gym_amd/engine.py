@@ -9,6 +9,8 @@ import numpy as np
 from . import _lib as L
 
 _NP = {L.F32: np.float32, L.F64: np.float64, L.I32: np.int32, L.U8: np.uint8}
+# gx_transition as a numpy record
+TRANSITION_DTYPE = np.dtype([("next_state", np.int32), ("reward", np.float32), ("done", np.int32)])
 
 
 class Context:
@@ -48,13 +50,23 @@ class DeviceBatch:
     """A batch of `num_envs` environments resident in HBM (VectorEnv.cs:10-35)."""
 
     def __init__(self, ctx, env_id, num_envs, seed=0, flags=0, time_limit=0, mode=L.MODE_EXACT, map_rows=None,
-                 env_index_base=0):
+                 env_index_base=0, table=None, n_outcomes=1, start_state=0, step_limit=0):
+        """table (env_id L.ENV_TABLE only): transitions as a numpy structured array of TRANSITION_DTYPE, shape
+        [n_states, n_actions] or [n_states, n_actions, n_outcomes]; start_state -1 resets to a uniform draw over the
+        states; step_limit 0 = the env never ends by its own step counter"""
         lib = L.load()
         self.ctx = ctx
         rows = None
         if map_rows is not None:
             rows = map_rows.encode() if isinstance(map_rows, str) else "/".join(map_rows).encode()
         d = L.GxDesc(C.sizeof(L.GxDesc), env_id, num_envs, seed, env_index_base, mode, flags, time_limit, 0, rows)
+        if table is not None:
+            t = np.ascontiguousarray(table, dtype=TRANSITION_DTYPE)
+            if t.ndim not in (2, 3):
+                raise ValueError("table must have shape [n_states, n_actions] or [n_states, n_actions, n_outcomes]")
+            d.table, d.table_len = t.ctypes.data, t.size
+            d.n_states, d.n_actions, d.n_outcomes = t.shape[0], t.shape[1], n_outcomes
+            d.start_state, d.step_limit = start_state, step_limit
         self._h = C.c_void_p()
         L.check(lib.gx_vec_create(ctx._h, C.byref(d), C.byref(self._h)))
         self.info = L.GxInfo()

@@ -50,13 +50,18 @@ class DeviceEnv(Env):
             from .engine import DeviceBatch
 
             self._batch = DeviceBatch(default_context(self._device), self.ENV_ID, 1, seed=self._seed, mode=self._mode,
-                                      flags=self._flags, map_rows=self._map_rows, env_index_base=self._stream)
+                                      flags=self._flags, map_rows=self._map_rows, env_index_base=self._stream,
+                                      **self._batch_extra())
         return self._batch
+
+    def _batch_extra(self):
+        """further DeviceBatch arguments of this env type (the caller-supplied table)"""
+        return {}
 
     def batch_config(self):
         """what VectorEnv needs to build one batch for a list of these envs"""
         return dict(env_id=self.ENV_ID, seed=self._seed, mode=self._mode, flags=self._flags, map_rows=self._map_rows,
-                    device=self._device)
+                    device=self._device, extra=self._batch_extra())
 
     def _state_of(self, obs, index=0):
         """observation arrays of a batch -> the reference's TState for env `index`"""
@@ -177,6 +182,53 @@ class FrozenLake(_IntStateEnv):
         rows = list(map) if map is not None else ["SFFF", "FHFH", "FFFH", "HFFG"]
         self.ActionSpace = Discrete(4)
         self.ObservationSpace = Discrete(len(rows) * len(rows[0]))
+
+
+class TableEnv(_IntStateEnv):
+    """Env<int,int> stepped from a transition table the caller supplies: what FrozenLake's `map` argument
+    (Envs.FrozenLake.cs:23) generalises to.  `table[s][a]` (or `[s][a][o]` with three equally likely outcomes) holds
+    (next_state, reward, done) records of engine.TRANSITION_DTYPE; Reset() sets `start_state` (-1: a uniform draw over
+    the states, as Envs.Taxi.cs:20); `step_limit` is the env's own `steps >= limit` term of done (0: none).  An action
+    outside Discrete(n_actions) raises IndexError, as an out-of-range index does in the reference."""
+    ENV_ID, ID = L.ENV_TABLE, None
+
+    def __init__(self, table, start_state=0, step_limit=0, **kw):
+        from .engine import TRANSITION_DTYPE
+
+        super().__init__(**kw)
+        t = np.ascontiguousarray(table, dtype=TRANSITION_DTYPE)
+        if t.ndim == 2:
+            t = t[:, :, None]
+        if t.ndim != 3:
+            raise ValueError("table must have shape [n_states, n_actions] or [n_states, n_actions, n_outcomes]")
+        self._table, self._start_state, self._step_limit = t, int(start_state), int(step_limit)
+        self.ActionSpace = Discrete(t.shape[1])
+        self.ObservationSpace = Discrete(t.shape[0])
+
+    def _batch_extra(self):
+        return dict(table=_TableKey(self._table), n_outcomes=self._table.shape[2], start_state=self._start_state,
+                    step_limit=self._step_limit)
+
+    def Step(self, action):
+        try:
+            return super().Step(action)
+        except L.GymxError as e:
+            if e.code == L.GX_ERR_INVALID:
+                raise IndexError(str(e))
+            raise
+
+
+class _TableKey:
+    """a table that compares by content, so that envs built from equal tables share a VectorEnv"""
+
+    def __init__(self, array):
+        self.array = array
+
+    def __eq__(self, other):
+        return isinstance(other, _TableKey) and self.array.shape == other.array.shape and self.array.tobytes() == other.array.tobytes()
+
+    def __array__(self, dtype=None, copy=None):
+        return self.array
 
 
 class Taxi(_IntStateEnv):

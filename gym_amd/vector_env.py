@@ -71,7 +71,7 @@ class VectorEnv:
         self._time_limit = time_limit
         self._batch = DeviceBatch(default_context(cfg["device"]), cfg["env_id"], n, seed=cfg["seed"], flags=flags,
                                   time_limit=time_limit, mode=cfg["mode"], map_rows=cfg["map_rows"],
-                                  env_index_base=env_index_base)
+                                  env_index_base=env_index_base, **cfg.get("extra", {}))
         self.ActionSpace = self._proto.ActionSpace
         self.ObservationSpace = self._proto.ObservationSpace
 

@@ -59,7 +59,9 @@ typedef enum gx_env_id {
   GX_ENV_BREAKOUT = 10,        /* "Breakout-v4"              Envs.Breakout.cs */
   GX_ENV_SPACEINVADERS = 11,   /* "SpaceInvaders-v4"         Envs.SpaceInvaders.cs */
   GX_ENV_BLACKJACK = 12,       /* "Blackjack-v1"             Envs.Blackjack.cs */
-  GX_ENV_COUNT = 13
+  GX_ENV_TABLE = 13,           /* a table-driven env whose transitions the caller supplies (gx_desc.table): what
+                                  FrozenLake's map argument (Envs.FrozenLake.cs:23) generalises to */
+  GX_ENV_COUNT = 14
 } gx_env_id;
 
 /* Numeric mode of the continuous-control kernels. */
@@ -98,6 +100,16 @@ typedef struct gx_ctx gx_ctx;
 typedef struct gx_vec gx_vec;
 typedef struct gx_comm gx_comm;
 
+/* One entry of a caller-supplied transition table (GX_ENV_TABLE): taking action a in state s moves the env
+ * to next_state, pays reward and ends the episode when done is non-zero -- the three things the bodies of
+ * FrozenLake.Step, CliffWalking.Step and Taxi.Step compute (Envs.FrozenLake.cs:52-69, Envs.CliffWalking.cs:36-54,
+ * Envs.Taxi.cs:25-33). */
+typedef struct gx_transition {
+  int32_t next_state; /* 0 .. n_states-1 */
+  float reward;
+  int32_t done;       /* non-zero: terminal */
+} gx_transition;
+
 /* Construction parameters of a batch (the reference has no configuration
  * beyond constructor arguments: Envs.FrozenLake.cs:23 map, TimeLimit maxSteps
  * Wrappers.TimeLimit.cs:11). */
@@ -114,7 +126,30 @@ typedef struct gx_desc {
   int32_t reserved;
   const char* map_rows;    /* FrozenLake rows joined by '/', NULL = default 4x4 map
                               (Envs.FrozenLake.cs:25-30), "8x8" = upstream's 8x8 map */
+  /* ---- GX_ENV_TABLE only (ignored, and may be left out of struct_size, for every other env) ----
+   * The library compiles the table into the packed form its built-in table-driven envs use and stages it in LDS
+   * (up to 64 KiB packed: (n_actions + 1) * n_states * n_outcomes + n_rewards words; larger tables are read through
+   * L2).  Copied at gx_vec_create; the caller's array is not kept. */
+  const gx_transition* table; /* [n_states][n_actions][n_outcomes], entry ((s * n_actions + a) * n_outcomes + o) */
+  uint64_t table_len;      /* n_states * n_actions * n_outcomes (checked) */
+  int32_t n_states;        /* 1 .. 65536; ObservationSpace is Discrete(n_states) */
+  int32_t n_actions;       /* 1 .. 255; ActionSpace is Discrete(n_actions).  An action outside it is an error as where the
+                              reference throws: GX_ERR_INVALID from gx_vec_step_async before any env is stepped; on the
+                              zero-copy path from the gx_vec_wait that follows (the env it was given to takes action 0) */
+  int32_t n_outcomes;      /* 1 (0 reads as 1): deterministic.  3: every step draws one of three equally likely outcomes,
+                              independent of the action, from the env's word of the tick (how GX_SLIPPERY compiles
+                              FrozenLake: outcome o of action a there is action (a + 3 + o) mod 4) */
+  int32_t start_state;     /* what Reset() sets: this state (Envs.FrozenLake.cs:47, Envs.CliffWalking.cs:31), or -1: a
+                              uniform draw over the states (Envs.Taxi.cs:20, Next(500)) */
+  int32_t step_limit;      /* the env's own `steps >= limit` term of done (Envs.FrozenLake.cs:65, Envs.Taxi.cs:29);
+                              0 = none.  Independent of time_limit, the TimeLimit wrapper's */
+  int32_t reserved2;
+  /* Rewards: at most 256 distinct values, finite.  With GX_RECORD_STATS they must be integers of magnitude at most
+   * 2^20 (every table-driven env of the reference pays integers; the fused statistics add them exactly), else
+   * GX_ERR_UNSUPPORTED. */
 } gx_desc;
+/* sizeof(gx_desc) of callers built before the GX_ENV_TABLE fields existed; still accepted for the other envs */
+#define GX_DESC_SIZE_V1 56u
 
 /* Static facts about a batch (what an agent reads from ActionSpace /
  * ObservationSpace, e.g. Envs.CartPole.cs:12-16). */
@@ -197,7 +232,7 @@ int gx_vec_reset(gx_vec* vec);
  *   Acrobot+RK4 (f64) theta1, theta2, dtheta1, dtheta2 | steps   (set_state: finite values, |theta| <= 1024,
  *                  else GX_ERR_INVALID; the next step wraps the angles to [-pi, pi])
  *   (the five above hold doubles under GX_MODE_FP64)
- *   tabular, Dummy   - | state, steps
+ *   tabular, Dummy, GX_ENV_TABLE   - | state, steps
  *   Blackjack        - | (playerSum*11 + dealerCard)*2 + usableAce (the index of ObservationSpace Discrete(704),
  *                  Envs.Blackjack.cs:13), dealer's face-down cards (raw sum | "an ace among them" << 8; 0 unless
  *                  GX_BLACKJACK_FULL), steps

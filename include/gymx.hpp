@@ -147,6 +147,12 @@ struct BatchOptions {
   std::string map_rows;        // FrozenLake rows joined by '/', "" = default
   uint64_t env_index_base = 0;
   int device = 0;
+  // GX_ENV_TABLE only: the caller's transitions [n_states][n_actions][n_outcomes] -- what FrozenLake's map
+  // argument (Envs.FrozenLake.cs:23) generalises to -- and the env's Reset() state and own step limit
+  std::vector<gx_transition> table;
+  int n_states = 0, n_actions = 0, n_outcomes = 1;
+  int start_state = 0;         // -1: a uniform draw over the states (Envs.Taxi.cs:20)
+  int step_limit = 0;          // 0: none
 };
 
 // One batch behind gx_vec_*; owns nothing but the handle.
@@ -163,6 +169,15 @@ class Batch {
     d.flags = o.extension_flags | (o.autoreset ? (uint32_t)GX_AUTORESET : 0u) | (o.record_stats ? (uint32_t)GX_RECORD_STATS : 0u);
     d.time_limit = o.time_limit;
     d.map_rows = o.map_rows.empty() ? nullptr : o.map_rows.c_str();
+    if (env_id == GX_ENV_TABLE) {
+      d.table = o.table.data();
+      d.table_len = o.table.size();
+      d.n_states = o.n_states;
+      d.n_actions = o.n_actions;
+      d.n_outcomes = o.n_outcomes;
+      d.start_state = o.start_state;
+      d.step_limit = o.step_limit;
+    }
     check(gx_vec_create(ctx_->handle(), &d, &h_));
     check(gx_vec_info(h_, &info_));
   }
@@ -176,8 +191,9 @@ class Batch {
   void Reset() { check(gx_vec_reset(h_)); }
   // host path: actions in, whatever is asked for out (VectorEnv.Step, VectorEnv.cs:28-34)
   void Step(const void* actions, void* obs, void* reward, uint8_t* done, uint8_t* truncated) {
-    check(gx_vec_step_async(h_, actions, obs, reward, done, truncated), info_.env_id == GX_ENV_ACROBOT);
-    check(gx_vec_wait(h_), info_.env_id == GX_ENV_ACROBOT);
+    const bool throws_on_action = info_.env_id == GX_ENV_ACROBOT || info_.env_id == GX_ENV_TABLE;
+    check(gx_vec_step_async(h_, actions, obs, reward, done, truncated), throws_on_action);
+    check(gx_vec_wait(h_), throws_on_action);
   }
   void GetObs(void* obs) { check(gx_vec_get_obs(h_, obs, info_.obs_bytes)); }
   std::vector<uint8_t> GetState() {

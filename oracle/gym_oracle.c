@@ -948,6 +948,63 @@ static void taxi_import(env_obj* e, const void* reals, const int32_t* ints) {
 }
 static const env_vtbl taxi_vt = {taxi_reset, taxi_step, taxi_export, taxi_import, sizeof(taxi_t)};
 
+/* ------------------------------------------------- caller-supplied tables */
+/* What FrozenLake's map argument (Envs.FrozenLake.cs:23) generalises to: the body of Step is a table lookup,
+ * the rest -- steps++, the step-limit term of done, Reset -- is as in Envs.FrozenLake.cs:45-69 / Envs.Taxi.cs:18-33. */
+typedef struct table_desc {
+  gxo_transition* t;
+  int32_t n_states, n_actions, n_outcomes, start_state, step_limit;
+} table_desc;
+
+typedef struct {
+  env_obj base;
+  const table_desc* d;
+  int32_t state;
+  int32_t steps;
+} table_t;
+
+static void table_reset(env_obj* e, const rng_ctx* r) {
+  table_t* c = (table_t*)e;
+  /* Envs.FrozenLake.cs:47 a fixed state; Envs.Taxi.cs:20 `_rng.Next(n)` */
+  c->state = c->d->start_state >= 0 ? c->d->start_state : gxo_rng_below(r->seed, r->env_index, r->tick, 0, 0, c->d->n_states);
+  c->steps = 0;
+}
+
+static int table_step(env_obj* e, const void* action, const rng_ctx* r, double* reward, int* done) {
+  table_t* c = (table_t*)e;
+  const table_desc* d = c->d;
+  int a = *(const int32_t*)action;
+  if (a < 0 || a >= d->n_actions) return -1;
+  int o = 0;
+  if (d->n_outcomes > 1) {
+    /* the digit that follows the action digit of the env's word of the tick (stream 3), as in grid_step */
+    uint64_t w = gxo_rng_u32(r->seed, r->env_index, r->tick, 3, 0);
+    o = (int)((w * (uint64_t)(d->n_actions * d->n_outcomes)) >> 32) - d->n_outcomes * (int)((w * (uint64_t)d->n_actions) >> 32);
+  }
+  /* a state outside the table (only reachable through set_state) is read as state 0 */
+  int s = c->state >= 0 && c->state < d->n_states ? c->state : 0;
+  const gxo_transition* t = &d->t[((size_t)s * d->n_actions + a) * d->n_outcomes + o];
+  c->state = t->next_state;
+  c->steps++;
+  *done = t->done != 0 || (d->step_limit > 0 && c->steps >= d->step_limit);
+  *reward = (double)t->reward;
+  return 0;
+}
+
+static void table_export(const env_obj* e, void* reals, int32_t* ints) {
+  (void)reals;
+  const table_t* c = (const table_t*)e;
+  ints[0] = c->state;
+  ints[1] = c->steps;
+}
+static void table_import(env_obj* e, const void* reals, const int32_t* ints) {
+  (void)reals;
+  table_t* c = (table_t*)e;
+  c->state = ints[0];
+  c->steps = ints[1];
+}
+static const env_vtbl table_vt = {table_reset, table_step, table_export, table_import, sizeof(table_t)};
+
 /* ------------------------------------------------------------------- Dummy */
 typedef struct {
   env_obj base;
@@ -1732,6 +1789,7 @@ struct gxo_vec {
   uint64_t tick;
   env_obj** envs;
   grid_desc* grid;
+  table_desc* table;
   int n_real, real_is_f64, obs_is_f64, n_int, obs_dim, action_is_float;
   /* Wrappers.TimeLimit.cs:9 `_steps` per env */
   int32_t* tl_steps;
@@ -1772,10 +1830,38 @@ static int parse_map(grid_desc* g, const char* rows) {
 
 static const char* const FROZENLAKE_4X4 = "SFFF/FHFH/FFFH/HFFG"; /* Envs.FrozenLake.cs:25-30 */
 
+static gxo_vec* vec_create(int env_id, uint64_t num_envs, uint64_t seed, uint32_t flags, int32_t time_limit,
+                           const char* map_rows, uint64_t env_index_base, table_desc* table);
+
 gxo_vec* gxo_vec_create(int env_id, uint64_t num_envs, uint64_t seed, uint32_t flags, int32_t time_limit,
                         const char* map_rows, uint64_t env_index_base) {
+  if (env_id == GXO_TABLE) return NULL; /* gxo_vec_create_table */
+  return vec_create(env_id, num_envs, seed, flags, time_limit, map_rows, env_index_base, NULL);
+}
+
+gxo_vec* gxo_vec_create_table(uint64_t num_envs, uint64_t seed, uint32_t flags, int32_t time_limit, uint64_t env_index_base,
+                              const gxo_transition* table, int32_t n_states, int32_t n_actions, int32_t n_outcomes,
+                              int32_t start_state, int32_t step_limit) {
+  if (n_outcomes == 0) n_outcomes = 1;
+  if (!table || n_states < 1 || n_states > 65536 || n_actions < 1 || n_actions > 255 || (n_outcomes != 1 && n_outcomes != 3) ||
+      start_state < -1 || start_state >= n_states || step_limit < 0)
+    return NULL;
+  const size_t len = (size_t)n_states * n_actions * n_outcomes;
+  for (size_t i = 0; i < len; i++)
+    if (table[i].next_state < 0 || table[i].next_state >= n_states) return NULL;
+  table_desc* d = (table_desc*)calloc(1, sizeof *d);
+  d->t = (gxo_transition*)malloc(len * sizeof *d->t);
+  memcpy(d->t, table, len * sizeof *d->t);
+  d->n_states = n_states; d->n_actions = n_actions; d->n_outcomes = n_outcomes;
+  d->start_state = start_state; d->step_limit = step_limit;
+  return vec_create(GXO_TABLE, num_envs, seed, flags, time_limit, NULL, env_index_base, d);
+}
+
+static gxo_vec* vec_create(int env_id, uint64_t num_envs, uint64_t seed, uint32_t flags, int32_t time_limit,
+                           const char* map_rows, uint64_t env_index_base, table_desc* table) {
   if (env_id < 0 || env_id >= GXO_NUM_ENVS) return NULL;
   gxo_vec* v = (gxo_vec*)calloc(1, sizeof *v);
+  v->table = table;
   v->env_id = env_id;
   v->n = num_envs;
   v->seed = seed;
@@ -1800,6 +1886,7 @@ gxo_vec* gxo_vec_create(int env_id, uint64_t num_envs, uint64_t seed, uint32_t f
     case GXO_BREAKOUT: vt = &breakout_vt; v->n_real = 5; v->real_is_f64 = 1; v->n_int = 8; v->obs_dim = GXO_PONG_FRAME_BYTES; break;
     case GXO_SPACEINVADERS: vt = &invaders_vt; v->n_real = 13; v->real_is_f64 = 1; v->n_int = 9; v->obs_dim = GXO_PONG_FRAME_BYTES; break;
     case GXO_BLACKJACK: vt = &blackjack_vt; v->n_real = 0; v->n_int = 3; v->obs_dim = 1; break;
+    case GXO_TABLE: vt = &table_vt; v->n_real = 0; v->n_int = 2; v->obs_dim = 1; break;
   }
   int classic64 = 0;
   if ((flags & GXO_FP64) && env_id <= GXO_ACROBOT && !(env_id == GXO_ACROBOT && (flags & GXO_ACROBOT_RK4))) {
@@ -1833,6 +1920,7 @@ gxo_vec* gxo_vec_create(int env_id, uint64_t num_envs, uint64_t seed, uint32_t f
     env_obj* e = (env_obj*)calloc(1, vt->size);
     e->vt = vt;
     if (v->grid) ((grid_t*)e)->g = v->grid;
+    if (v->table) ((table_t*)e)->d = v->table;
     if (env_id == GXO_TAXI) ((taxi_t*)e)->full = (flags & GXO_TAXI_FULL) != 0;
     if (env_id == GXO_BLACKJACK) ((blackjack_t*)e)->full = (flags & GXO_BLACKJACK_FULL) != 0;
     if (classic64) ((classic64_t*)e)->n = v->n_real;
@@ -1863,6 +1951,8 @@ void gxo_vec_destroy(gxo_vec* v) {
   }
   free(v->envs);
   free(v->grid);
+  if (v->table) free(v->table->t);
+  free(v->table);
   free(v->tl_steps);
   free(v->cur_reward);
   free(v->cur_length);
@@ -1954,10 +2044,10 @@ static int vec_step_impl(gxo_vec* v, const void* actions, int random_policy, voi
           af = gxo_box_sample(u, -2.0f, 2.0f);
           break;
         default: {
-          static const int nact[GXO_NUM_ENVS] = {2, 3, 0, 0, 3, 4, 6, 4, 4, 3, 4, 6, 2};
+          static const int nact[GXO_NUM_ENVS] = {2, 3, 0, 0, 3, 4, 6, 4, 4, 3, 4, 6, 2, 0};
           const int tabular = v->env_id == GXO_FROZENLAKE || v->env_id == GXO_TAXI || v->env_id == GXO_CLIFFWALKING || v->env_id == GXO_DUMMY ||
-                              v->env_id == GXO_BLACKJACK;
-          ai = gxo_rng_below(r.seed, r.env_index, r.tick, tabular ? 3 : 2, 0, nact[v->env_id]);
+                              v->env_id == GXO_BLACKJACK || v->env_id == GXO_TABLE;
+          ai = gxo_rng_below(r.seed, r.env_index, r.tick, tabular ? 3 : 2, 0, v->table ? v->table->n_actions : nact[v->env_id]);
         }
       }
       if (v->action_is_float) {

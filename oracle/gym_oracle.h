@@ -44,7 +44,9 @@ enum {
   GXO_BREAKOUT = 10,     /* Envs.Breakout.cs */
   GXO_SPACEINVADERS = 11, /* Envs.SpaceInvaders.cs */
   GXO_BLACKJACK = 12,    /* Envs.Blackjack.cs */
-  GXO_NUM_ENVS = 13
+  GXO_TABLE = 13,        /* an env stepped from a transition table the caller supplies (gxo_vec_create_table): the
+                            shape of FrozenLake.Step / CliffWalking.Step / Taxi.Step with the table for their bodies */
+  GXO_NUM_ENVS = 14
 };
 
 /* Wrapper / engine flags. */
@@ -82,6 +84,19 @@ int32_t gxo_rng_below(uint64_t seed, uint64_t env_index, uint64_t tick, uint32_t
 float gxo_box_sample(double u, float low, float high);
 
 /* ---- batched engine shaped like VectorEnv.cs:10-35 */
+/* One entry of a transition table, as include/gymx.h's gx_transition. */
+typedef struct gxo_transition {
+  int32_t next_state;
+  float reward;
+  int32_t done;
+} gxo_transition;
+/* GXO_TABLE: table[((s * n_actions + a) * n_outcomes + o)], n_outcomes 1 or 3 (equally likely, drawn per step from
+ * the env's word of the tick like the slippery FrozenLake's), Reset() to start_state or, for -1, to a uniform draw
+ * over the states, done also when the env's own step counter reaches step_limit (0: never).  An action outside
+ * [0, n_actions) makes gxo_vec_step return -1.  The table is copied.  NULL when an argument is out of range. */
+gxo_vec* gxo_vec_create_table(uint64_t num_envs, uint64_t seed, uint32_t flags, int32_t time_limit, uint64_t env_index_base,
+                              const gxo_transition* table, int32_t n_states, int32_t n_actions, int32_t n_outcomes,
+                              int32_t start_state, int32_t step_limit);
 gxo_vec* gxo_vec_create(int env_id, uint64_t num_envs, uint64_t seed, uint32_t flags,
                         int32_t time_limit, const char* map_rows, uint64_t env_index_base);
 void gxo_vec_destroy(gxo_vec* v);

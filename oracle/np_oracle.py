@@ -417,6 +417,21 @@ def taxi_step(state, steps, action):
     return state, steps, np.full(state.shape, -1.0), steps >= 200
 
 
+def table_step(state, steps, action, table, n_outcomes=1, step_limit=0, rng=None):
+    """An env stepped from a caller-supplied transition table (include/gymx.h GX_ENV_TABLE): the lookup stands for the
+    body of FrozenLake.Step / Taxi.Step, the rest is Envs.FrozenLake.cs:64-68.  table: structured array
+    [n_states, n_actions, n_outcomes] of (next_state, reward, done); rng = (seed, env, tick) when n_outcomes > 1."""
+    table = np.asarray(table).reshape(table.shape[0], table.shape[1], -1)
+    a = np.asarray(action)
+    assert ((a >= 0) & (a < table.shape[1])).all()
+    o = slip_outcome(*rng, n_act=table.shape[1], n_out=n_outcomes) if n_outcomes > 1 else np.zeros(a.shape, np.int32)
+    s = np.where((state >= 0) & (state < table.shape[0]), state, 0)
+    t = table[s, a, o]
+    steps = steps + 1
+    done = (t["done"] != 0) | ((steps >= step_limit) if step_limit > 0 else False)
+    return t["next_state"].astype(np.int32), steps, t["reward"].astype(f64), done
+
+
 def dummy_step(state, steps, action):
     """DummyEnv.cs:23-30"""
     ns = (state + np.asarray(action, np.int32)).astype(np.int32)

@@ -13,10 +13,18 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libgym_oracle.so")
 
 (CARTPOLE, MOUNTAINCAR, MOUNTAINCAR_CONT, PENDULUM, ACROBOT, FROZENLAKE, TAXI, CLIFFWALKING, PONG, DUMMY,
- BREAKOUT, SPACEINVADERS, BLACKJACK) = range(13)
+ BREAKOUT, SPACEINVADERS, BLACKJACK, TABLE) = range(14)
 AUTORESET, RECORD_STATS, SLIPPERY, TAXI_FULL, ACROBOT_RK4, FP64, BLACKJACK_FULL = 1, 2, 4, 8, 16, 32, 64
 PONG_FRAME_BYTES = 210 * 160 * 3
 FLOAT_ACTION = {MOUNTAINCAR_CONT, PENDULUM}
+
+
+class Transition(C.Structure):
+    """gxo_transition: one entry of a caller-supplied table"""
+    _fields_ = [("next_state", C.c_int32), ("reward", C.c_float), ("done", C.c_int32)]
+
+
+TRANSITION_DTYPE = np.dtype([("next_state", np.int32), ("reward", np.float32), ("done", np.int32)])
 
 
 class Stats(C.Structure):
@@ -65,6 +73,8 @@ def lib():
     L.gxo_box_sample.argtypes = [dbl, C.c_float, C.c_float]
     L.gxo_vec_create.restype = vp
     L.gxo_vec_create.argtypes = [C.c_int, u64, u64, u32, i32, C.c_char_p, u64]
+    L.gxo_vec_create_table.restype = vp
+    L.gxo_vec_create_table.argtypes = [u64, u64, u32, i32, u64, vp, i32, i32, i32, i32, i32]
     L.gxo_vec_destroy.argtypes = [vp]
     for name in ("num_envs", "tick"):
         getattr(L, "gxo_vec_" + name).restype = u64
@@ -106,10 +116,18 @@ def _ptr(a):
 class OracleVec:
     """Batched CPU engine shaped like the reference VectorEnv (VectorEnv.cs:10-35)."""
 
-    def __init__(self, env_id, num_envs, seed=0, flags=0, time_limit=0, map_rows=None, env_index_base=0):
+    def __init__(self, env_id, num_envs, seed=0, flags=0, time_limit=0, map_rows=None, env_index_base=0, table=None,
+                 n_outcomes=1, start_state=0, step_limit=0):
+        """table (env_id TABLE only): array of TRANSITION_DTYPE, shape [n_states, n_actions] or
+        [n_states, n_actions, n_outcomes]"""
         L = lib()
         rows = None if map_rows is None else "/".join(map_rows).encode()
-        self._h = L.gxo_vec_create(env_id, num_envs, seed, flags, time_limit, rows, env_index_base)
+        if env_id == TABLE:
+            t = np.ascontiguousarray(table, dtype=TRANSITION_DTYPE)
+            self._h = L.gxo_vec_create_table(num_envs, seed, flags, time_limit, env_index_base, _ptr(t), t.shape[0], t.shape[1],
+                                             n_outcomes, start_state, step_limit)
+        else:
+            self._h = L.gxo_vec_create(env_id, num_envs, seed, flags, time_limit, rows, env_index_base)
         if not self._h:
             raise ValueError("oracle: cannot create env %r" % (env_id,))
         self.env_id = env_id

@@ -250,6 +250,54 @@ static void supplied_draws() {
   std::printf("Batch(Pong) x 5: Reset() with supplied draws equals the source's formula and the oracle\n");
 }
 
+// A caller-supplied transition table through gymx::Batch: the reference's CliffWalking written out as P[s][a]
+// (Envs.CliffWalking.cs:36-54) gives the source's known answers, the oracle's table env the same, and an
+// action outside the space throws like the reference's out-of-range index.
+static void caller_supplied_table() {
+  const uint64_t n = 3;
+  BatchOptions o;
+  o.n_states = 48; o.n_actions = 4; o.start_state = 36; o.step_limit = 100;
+  o.table.resize(48 * 4);
+  for (int s = 0; s < 48; s++)
+    for (int a = 0; a < 4; a++) {
+      int row = s / 12, col = s % 12;
+      if (a == 0) col = std::max(col - 1, 0);
+      if (a == 1) row = std::min(row + 1, 3);
+      if (a == 2) col = std::min(col + 1, 11);
+      if (a == 3) row = std::max(row - 1, 0);
+      const int ns = row * 12 + col;
+      const bool cliff = ns >= 37 && ns <= 46, goal = ns == 47;
+      o.table[(size_t)s * 4 + a] = gx_transition{ns, goal ? 0.0f : (cliff ? -100.0f : -1.0f), (cliff || goal) ? 1 : 0};
+    }
+  Batch b(GX_ENV_TABLE, n, o);
+  CHECK(b.info().action_n == 4 && b.info().obs_dtype == GX_I32);
+  gxo_vec* ref = gxo_vec_create_table(n, 0, 0, 0, 0, reinterpret_cast<const gxo_transition*>(o.table.data()), 48, 4, 1, 36, 100);
+  CHECK(ref != nullptr);
+  b.Reset();
+  gxo_vec_reset(ref);
+  // env 0 walks up, along the top of the cliff and down into the goal; env 1 steps onto the cliff; env 2 pushes left
+  std::vector<int32_t> obs(n), act(n);
+  std::vector<float> rew(n);
+  std::vector<double> orew(n);
+  std::vector<uint8_t> done(n), odone(n);
+  double ret0 = 0;
+  for (int t = 0; t < 13; t++) {
+    act = {t == 0 ? 3 : (t < 12 ? 2 : 1), 2, 0};
+    b.Step(act.data(), obs.data(), rew.data(), done.data(), nullptr);
+    gxo_vec_step(ref, act.data(), orew.data(), odone.data(), nullptr);
+    for (uint64_t i = 0; i < n; i++) CHECK((double)rew[i] == orew[i] && done[i] == odone[i]);
+    ret0 += rew[0];
+    if (t == 0) CHECK(obs[0] == 24 && obs[1] == 37 && rew[1] == -100.0f && done[1] && obs[2] == 36 && !done[2]);
+  }
+  CHECK(obs[0] == 47 && done[0] && ret0 == -12.0);  // 12 steps at -1, the goal pays 0
+  bool threw = false;
+  act = {0, 4, 0};
+  try { b.Step(act.data(), obs.data(), rew.data(), done.data(), nullptr); } catch (const std::out_of_range&) { threw = true; }
+  CHECK(threw);
+  gxo_vec_destroy(ref);
+  std::printf("Batch(caller-supplied table: CliffWalking as P[s][a]) x 3: the source's known answers, equal to the oracle\n");
+}
+
 int main() {
   int count = 0;
   if (gx_device_count(&count) != GX_OK || count == 0) {
@@ -264,6 +312,7 @@ int main() {
   wrappers();
   fp64_mode();
   supplied_draws();
+  caller_supplied_table();
   std::printf(failures ? "FAILED (%d)\n" : "ALL OK\n", failures);
   return failures ? 1 : 0;
 }

@@ -38,14 +38,14 @@ def test_enum_values_in_sync(oracle):
                   ("ENV_ACROBOT", "GX_ENV_ACROBOT"), ("ENV_FROZENLAKE", "GX_ENV_FROZENLAKE"), ("ENV_TAXI", "GX_ENV_TAXI"),
                   ("ENV_CLIFFWALKING", "GX_ENV_CLIFFWALKING"), ("ENV_PONG", "GX_ENV_PONG"), ("ENV_DUMMY", "GX_ENV_DUMMY"),
                   ("ENV_BREAKOUT", "GX_ENV_BREAKOUT"), ("ENV_SPACEINVADERS", "GX_ENV_SPACEINVADERS"),
-                  ("ENV_BLACKJACK", "GX_ENV_BLACKJACK"), ("BLACKJACK_FULL", "GX_BLACKJACK_FULL"),
+                  ("ENV_BLACKJACK", "GX_ENV_BLACKJACK"), ("ENV_TABLE", "GX_ENV_TABLE"), ("BLACKJACK_FULL", "GX_BLACKJACK_FULL"),
                   ("AUTORESET", "GX_AUTORESET"), ("RECORD_STATS", "GX_RECORD_STATS"), ("SLIPPERY", "GX_SLIPPERY"),
                   ("TAXI_FULL", "GX_TAXI_FULL"), ("ACROBOT_RK4", "GX_ACROBOT_RK4"), ("GX_ERR_INVALID", "GX_ERR_INVALID"),
                   ("GX_ERR_RCCL", "GX_ERR_RCCL"), ("POLICY_RANDOM", "GX_POLICY_RANDOM"), ("MODE_FAST32", "GX_MODE_FAST32")]:
         assert getattr(L, py) == enum(c), py
     # the oracle numbers envs and flags the same way
     for name in ("CARTPOLE", "MOUNTAINCAR", "MOUNTAINCAR_CONT", "PENDULUM", "ACROBOT", "FROZENLAKE", "TAXI",
-                 "CLIFFWALKING", "PONG", "DUMMY", "BREAKOUT", "SPACEINVADERS", "BLACKJACK"):
+                 "CLIFFWALKING", "PONG", "DUMMY", "BREAKOUT", "SPACEINVADERS", "BLACKJACK", "TABLE"):
         assert getattr(oracle, name) == getattr(L, "ENV_" + name)
     for name in ("AUTORESET", "RECORD_STATS", "SLIPPERY", "TAXI_FULL", "ACROBOT_RK4", "BLACKJACK_FULL"):
         assert getattr(oracle, name) == getattr(L, name)
@@ -53,7 +53,9 @@ def test_enum_values_in_sync(oracle):
 
 def test_struct_sizes_match_header():
     # natural alignment on x86-64 / the layout a C# [StructLayout(Sequential)] mirror gets
-    assert C.sizeof(L.GxDesc) == 56
+    assert C.sizeof(L.GxDesc) == 96 and L.GxDesc.table.offset == 56 == L.DESC_SIZE_V1
+    assert int(re.search(r"#define GX_DESC_SIZE_V1 (\d+)u", HEADER).group(1)) == L.DESC_SIZE_V1
+    assert C.sizeof(L.GxTransition) == 12
     assert C.sizeof(L.GxStats) == 48
     assert C.sizeof(L.GxView) == 64
     assert C.sizeof(L.GxInfo) == 72

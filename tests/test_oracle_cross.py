@@ -433,3 +433,47 @@ def test_wrappers_match_numpy_restatement(oracle):
             assert d == bool(done[i]) and tr == bool(trunc[i])
     for i in range(n):
         assert v.episodes(i) == list(zip(res[i].episode_rewards, res[i].episode_lengths))
+
+
+def test_table_env_bitwise_and_equal_to_the_envs_it_generalises(oracle):
+    """the oracle's caller-supplied-table env: the C and numpy restatements agree, and FrozenLake / CliffWalking /
+    the Taxi stub written out as P[s][a] step exactly like the oracle's envs of those ids"""
+    import tables as T
+
+    rng = np.random.default_rng(21)
+    n = 2000
+    env = np.arange(n, dtype=np.uint64)
+    for n_out in (1, 3):
+        table = T.random_table(rng, 300, 5, n_out)
+        v = oracle.OracleVec(oracle.TABLE, n, seed=SEED, table=table, n_outcomes=n_out, start_state=-1, step_limit=40)
+        v.reset()
+        st = NP.rng_below(SEED, env, 0, 0, 0, 300).astype(np.int32)
+        assert np.array_equal(v.get_obs(), st)
+        steps = np.zeros(n, np.int32)
+        for t in range(50):
+            a = rng.integers(0, 5, n).astype(np.int32)
+            rew, done, _ = v.step(a)
+            st, steps, rew2, done2 = NP.table_step(st, steps, a, table, n_out, 40, rng=(SEED, env, t + 1))
+            assert np.array_equal(v.get_obs(), st) and np.array_equal(rew, rew2) and np.array_equal(done.astype(bool), done2)
+    cases = [(oracle.FROZENLAKE, 0, None, T.frozenlake(T.MAP4), dict(start_state=0, step_limit=100)),
+             (oracle.FROZENLAKE, oracle.SLIPPERY, T.MAP8, T.frozenlake(T.MAP8, True), dict(start_state=0, step_limit=100, n_outcomes=3)),
+             (oracle.CLIFFWALKING, 0, None, T.cliffwalking(), dict(start_state=36, step_limit=100)),
+             (oracle.TAXI, 0, None, T.taxi_stub(), dict(start_state=-1, step_limit=200))]
+    flags = oracle.AUTORESET | oracle.RECORD_STATS
+    for env_id, xf, rows, table, kw in cases:
+        a_n = table.shape[1]
+        ref = oracle.OracleVec(env_id, n, seed=SEED, flags=flags | xf, map_rows=rows)
+        tab = oracle.OracleVec(oracle.TABLE, n, seed=SEED, flags=flags, table=table, **kw)
+        ref.reset(); tab.reset()
+        for t in range(220):
+            a = rng.integers(0, a_n, n).astype(np.int32)
+            r1, d1, _ = ref.step(a)
+            r2, d2, _ = tab.step(a)
+            assert np.array_equal(r1, r2) and np.array_equal(d1, d2) and np.array_equal(ref.get_obs(), tab.get_obs())
+        s1, s2 = ref.stats(), tab.stats()
+        assert (s1.episodes, s1.sum_return, s1.sum_length) == (s2.episodes, s2.sum_return, s2.sum_length) and s1.episodes > 0
+    # out-of-range action and arguments
+    with pytest.raises(IndexError):
+        tab.step(np.full(n, 6, np.int32))
+    with pytest.raises(ValueError):
+        oracle.OracleVec(oracle.TABLE, 4, table=T.taxi_stub(), start_state=500)
