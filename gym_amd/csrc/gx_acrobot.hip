@@ -18,11 +18,31 @@ namespace gx {
 #ifndef GX_ACROBOT_ANGLES_WAVES
 #define GX_ACROBOT_ANGLES_WAVES 4
 #endif
+// EXACT: the table-driven routines (these kernels are bound by instruction issue, and five sin/cos evaluations are
+// most of a step); FAST32: the binary32 ones.  Arguments are always bounded (kAlwaysBounded below).
+template <int MODE>
+struct AcrobotTrigOf {
+  using type = Trig<MODE, true>;
+};
+template <>
+struct AcrobotTrigOf<GX_MODE_EXACT> {
+  using type = TrigTable;
+};
+#ifdef GX_ACROBOT_NO_TABLE  // A/B builds only: the polynomial routines with quadrant selection
+template <int MODE>
+using AcrobotTrig = Trig<MODE, true>;
+constexpr bool kAcrobotSinCosTable = false;
+#else
+template <int MODE>
+using AcrobotTrig = typename AcrobotTrigOf<MODE>::type;
+constexpr bool kAcrobotSinCosTable = true;
+#endif
+
 // Envs.Acrobot.cs:36-74: from the two angles and their velocities to the values after one step (the angles
 // are not wrapped: the source keeps their cosines and sines).
 template <int MODE, bool BOUNDED>
 static __device__ __forceinline__ void acrobot_integrate(float& theta1, float& theta2, float& dtheta1, float& dtheta2, int32_t action) {
-  using T = Trig<MODE, BOUNDED>;
+  using T = AcrobotTrig<MODE>;
   const float LINK_LENGTH_1 = 1.0f;
   const float LINK_MASS_1 = 1.0f;
   const float LINK_MASS_2 = 1.0f;
@@ -85,7 +105,7 @@ static __device__ __forceinline__ void acrobot_integrate(float& theta1, float& t
 // within 1e-5 of the threshold needs the expression evaluated as the source writes it.
 template <int MODE, bool BOUNDED>
 static __device__ __forceinline__ bool acrobot_tip_above(float theta1, float theta2, float c1n, float s1n, float c2n, float s2n) {
-  using T = Trig<MODE, BOUNDED>;
+  using T = AcrobotTrig<MODE>;
   const float LINK_LENGTH_1 = 1.0f;
   const float LINK_LENGTH_2 = 1.0f;
   bool above;
@@ -114,6 +134,7 @@ struct Acrobot {
   // both angles come out of atan2 every step and the velocities are clamped to 4pi / 9pi
   // before they are integrated (Envs.Acrobot.cs:47-48,71-74): every angle is below 15
   static constexpr bool kAlwaysBounded = true;
+  static constexpr bool kSinCosTable = kAcrobotSinCosTable;
   // reward -1 on every step but the final one (Envs.Acrobot.cs:88)
   static constexpr int kStepReturn = -1;
 
@@ -131,7 +152,7 @@ struct Acrobot {
   // the kernel treats such a lane as torque 0 and raises the error flag.
   template <int MODE, bool BOUNDED>
   static __device__ __forceinline__ void step(float (&s)[NS], int32_t& steps, Act action, Rew& reward, bool& done) {
-    using T = Trig<MODE, BOUNDED>;
+    using T = AcrobotTrig<MODE>;
     float theta1 = T::atan2(s[1], s[0]);
     float theta2 = T::atan2(s[3], s[2]);
     float dtheta1 = s[4];
@@ -176,8 +197,9 @@ struct AcrobotAngles {
   static constexpr bool kCheckAction = true;
   static __device__ __forceinline__ bool action_valid(Act a) { return (uint32_t)a <= 2u; }
   static constexpr bool kAlwaysBounded = true;
+  static constexpr bool kSinCosTable = kAcrobotSinCosTable;
   static constexpr int kStepReturn = -1;
-  using T = Trig<GX_MODE_EXACT, true>;
+  using T = AcrobotTrig<GX_MODE_EXACT>;
 
   // the angles as the source's step would read them out of the stored cosines and sines (Envs.Acrobot.cs:36-37)
   static __device__ __forceinline__ void derive(float (&s)[NS]) {
@@ -204,8 +226,13 @@ struct AcrobotAngles {
 
     // T::sincos with the binary64 values kept for the angle
     double S1, C1, S2, C2;
+#ifdef GX_ACROBOT_NO_TABLE
     math::sincos_bounded((double)theta1, S1, C1);
     math::sincos_bounded((double)theta2, S2, C2);
+#else
+    TrigTable::sincos64((double)theta1, S1, C1);
+    TrigTable::sincos64((double)theta2, S2, C2);
+#endif
     const float c1n = (float)C1, s1n = (float)S1, c2n = (float)C2, s2n = (float)S2;
     s[0] = c1n; s[1] = s1n; s[2] = c2n; s[3] = s2n; s[4] = dtheta1; s[5] = dtheta2;
     s[6] = math::atan2_of_rounded_sincos(theta1, S1, C1, s1n, c1n);

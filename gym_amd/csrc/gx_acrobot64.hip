@@ -14,8 +14,8 @@
 //
 // Every a*b+c is an explicit fma() (and nothing else is contracted) so that a
 // CPU restatement written with the same fma() calls can match wherever the
-// sin/cos results agree; sin and cos come from the reduction-light binary64
-// routine of gx_math.h (a few units in the last place, so results differ from
+// sin/cos results agree; sin and cos come from the table-driven binary64
+// routine of gx_math.h (within a unit in the last place, so results differ from
 // a libm build by parts in 10^16).
 #pragma clang fp contract(off)
 
@@ -40,10 +40,18 @@ struct Acrobot64 {
   // every sin/cos argument of an RK4 stage stays below 16 for any finite state
   static constexpr bool kAlwaysBounded = true;
   static constexpr int kStepReturn = -1;  // reward -1 on every step but the final one
+#ifdef GX_ACROBOT_NO_TABLE  // A/B builds only: the polynomial routine with quadrant selection
+  static constexpr bool kSinCosTable = false;
+  static __device__ __forceinline__ void sincos(double x, double& s, double& c) { math::sincos_reduced(x, s, c); }
+#else
+  // eight sin/cos pairs per step are two thirds of its instructions: the table-driven routine (gx_math.h)
+  static constexpr bool kSinCosTable = true;
+  static __device__ __forceinline__ void sincos(double x, double& s, double& c) { TrigTable::sincos64(x, s, c); }
+#endif
 
   static __device__ __forceinline__ void derive(double (&s)[NR]) {
-    math::sincos_reduced(s[0], s[4], s[5]);
-    math::sincos_reduced(s[1], s[6], s[7]);
+    sincos(s[0], s[4], s[5]);
+    sincos(s[1], s[6], s[7]);
   }
 
   static __device__ __forceinline__ void reset(double (&s)[NR], const RngKey& key, uint64_t env) {
@@ -61,8 +69,8 @@ struct Acrobot64 {
   // sin(theta1 + theta2) = s1 c2 + c1 s2.
   static __device__ __forceinline__ void dsdt(const double (&y)[4], double u, double (&dy)[4]) {
     double s1, c1, s2, c2;
-    math::sincos_reduced(y[0], s1, c1);
-    math::sincos_reduced(y[1], s2, c2);
+    sincos(y[0], s1, c1);
+    sincos(y[1], s2, c2);
     dsdt(y[2], y[3], s1, c1, s2, c2, u, dy);
   }
   static __device__ __forceinline__ void dsdt(double w1, double w2, double s1, double c1, double s2, double c2, double u,

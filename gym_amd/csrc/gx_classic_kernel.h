@@ -180,6 +180,17 @@ struct StateInLds<E, std::void_t<decltype(E::kStateInLds)>> {
   static constexpr bool value = E::kStateInLds;
 };
 
+// E::kSinCosTable: the env's EXACT arithmetic evaluates sin and cos through the LDS table of gx_trig.h, which every
+// kernel that runs its step, reset or derive fills first.
+template <class E, class = void>
+struct UsesSinCosTable {
+  static constexpr bool value = false;
+};
+template <class E>
+struct UsesSinCosTable<E, std::void_t<decltype(E::kSinCosTable)>> {
+  static constexpr bool value = E::kSinCosTable;
+};
+
 // minimum resident waves per SIMD the fused kernels are compiled for (caps their registers): E::kMinWaves, else 1
 #ifndef GX_FUSED_MIN_WAVES
 #define GX_FUSED_MIN_WAVES 1
@@ -214,6 +225,7 @@ __global__ void __launch_bounds__(kClassicBlock, (FUSED && BOUNDED) ? MinWaves<E
   static_assert(!PARK || (NR == NS && !E::kDerivedObs), "the LDS form holds the stored rows only");
   __shared__ Real parked[PARK ? NS : 1][W][kClassicBlock];
   const int lane = threadIdx.x;
+  if constexpr (UsesSinCosTable<E>::value && MODE == GX_MODE_EXACT) sincos_lds_fill();
 
   const bool autoreset = FUSED ? true : (a.flags & GX_AUTORESET) != 0;
   const bool record = FUSED ? true : (a.flags & GX_RECORD_STATS) != 0;
@@ -413,6 +425,7 @@ __global__ void __launch_bounds__(kClassicBlock) classic_reset_kernel(StepArgs a
   constexpr int W = E::W;
   Real* const sreal = static_cast<Real*>(a.state_real);
   const RngKey key = make_key(a.seed_lo, a.seed_hi, a.tick);
+  if constexpr (UsesSinCosTable<E>::value) sincos_lds_fill();
   const uint64_t ngroups = (a.num_envs + (W - 1)) / W;
   for (uint64_t q = (uint64_t)blockIdx.x * kClassicBlock + threadIdx.x; q < ngroups; q += (uint64_t)gridDim.x * kClassicBlock) {
     Real s[W][NR];
@@ -464,6 +477,7 @@ __global__ void __launch_bounds__(kClassicBlock) classic_derive_kernel(StepArgs 
   constexpr int NS = E::NS;
   constexpr int W = E::W;
   Real* const sreal = static_cast<Real*>(a.state_real);
+  if constexpr (UsesSinCosTable<E>::value) sincos_lds_fill();
   const uint64_t ngroups = (a.num_envs + (W - 1)) / W;
   for (uint64_t q = (uint64_t)blockIdx.x * kClassicBlock + threadIdx.x; q < ngroups; q += (uint64_t)gridDim.x * kClassicBlock) {
     Real s[W][NS];

@@ -7,6 +7,8 @@
 #include <stdint.h>
 #include <string.h>
 
+#include "gx_sincos_table.h"
+
 #if defined(__HIPCC__)
 #define GX_HD __host__ __device__ __forceinline__
 #else
@@ -150,6 +152,47 @@ GX_HD void sincos_reduced(double x, double& s, double& c) {
   double sn, cs;
   sincos_small(r, sn, cs);
   quadrant((int)(uint32_t)f64_bits(t), sn, cs, s, c);
+}
+
+// ---- table-driven sin and cos ----
+// sin(x) and cos(x) in binary64 to the last place (about 0.9 units, like the routines above) for |x| up to a
+// few thousand, at two thirds of their instruction count and with no quadrant logic: x = j pi/32 + r with
+// |r| <= pi/64 (Cody-Waite against pi/32 in three parts, the first of 33 bits so that j times it is exact),
+// sin and cos of the table angle a = j pi/32 read as head + tail from a 64-entry table (2 KiB: the kernels keep
+// it in LDS, the host checker in ordinary memory), short kernels for sin r and cos r - 1, and
+//   sin x = sin a + (cos a sin r + sin a (cos r - 1)),  cos x = cos a - (sin a sin r - cos a (cos r - 1)),
+// where the bracket is below 0.05: it is rounded at 2^-58 and the one rounding that shows is the final sum's.
+// Table entries at the multiples of pi/2 hold exact zeros, so the results keep their relative accuracy next to the
+// zeros of sin and cos (there the bracket alone is the result).  TAIL carries what the rounding of r dropped
+// (about 2^-58) into the result as well.
+struct alignas(32) SinCosEntry {
+  double sh, sl, ch, cl;  // sin a = sh + sl, cos a = ch + cl
+};
+
+template <bool TAIL>
+GX_HD void sincos_table(double x, const SinCosEntry* table, double& s, double& c) {
+  const double MAGIC = 0x1.8p+52;
+  // round(x * 32/pi) by adding and subtracting 1.5 * 2^52; the table index is in the sum's low bits
+  const double tq = fma(x, GX_SINCOS_INV_H, MAGIC);
+  const double fj = tq - MAGIC;
+  const double r0 = fma(-fj, GX_SINCOS_H1, x);  // exact
+  const double r = fma(-fj, GX_SINCOS_H2, r0);
+  const SinCosEntry e = table[(uint32_t)f64_bits(tq) & (GX_SINCOS_TABLE_ENTRIES - 1)];
+  const double z = r * r;
+  double p = fma_k(z, GX_SINCOS_S3, GX_SINCOS_S2);
+  p = fma_k(z, p, GX_SINCOS_S1);
+  double sr = fma(z * r, p, r);  // sin r
+  double q = fma_k(z, GX_SINCOS_C2, GX_SINCOS_C1);
+  q = fma_k(z, q, GX_SINCOS_C0);
+  double cm = z * q;             // cos r - 1
+  if (TAIL) {
+    double t = fma(-fj, GX_SINCOS_H2, r0 - r);
+    t = fma(-fj, GX_SINCOS_H3, t);
+    sr += t;              // sin(r + t) = sin r + t cos r, and t (1 - cos r) is below 2^-68
+    cm = fma(-r, t, cm);  // cos(r + t) = cos r - t sin r
+  }
+  s = e.sh + fma(e.ch, sr, fma(e.sh, cm, e.sl));
+  c = e.ch + fma(-e.sh, sr, fma(e.ch, cm, e.cl));
 }
 
 // 1 / x in binary64 to the last place or two (hardware estimate plus two Newton steps), for the

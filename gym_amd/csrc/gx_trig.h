@@ -27,6 +27,45 @@ namespace gx {
 template <int MODE, bool BOUNDED>
 struct Trig;
 
+// The 2 KiB table of math::sincos_table: a constant array in device memory, and the copy in LDS that the
+// kernels of the envs which use it fill once per workgroup (sincos_lds_fill, every thread of the workgroup
+// calls it before the first use) and read with two 16-byte LDS loads per evaluation.
+__attribute__((unused)) static __device__ const math::SinCosEntry g_sincos_table[GX_SINCOS_TABLE_ENTRIES] = GX_SINCOS_TABLE_VALUES;
+__device__ __forceinline__ math::SinCosEntry* sincos_lds() {
+  __shared__ math::SinCosEntry table[GX_SINCOS_TABLE_ENTRIES];
+  return table;
+}
+__device__ __forceinline__ void sincos_lds_fill() {
+  math::SinCosEntry* table = sincos_lds();
+  for (int i = threadIdx.x; i < GX_SINCOS_TABLE_ENTRIES; i += blockDim.x) table[i] = g_sincos_table[i];
+  __syncthreads();
+}
+
+// EXACT mode with bounded arguments through the table-driven routine (the same last-place accuracy as
+// Trig<GX_MODE_EXACT, true>, two thirds of its instructions, no quadrant selection).  For kernels that
+// are bound by instruction issue and have called sincos_lds_fill().
+struct TrigTable {
+  static __device__ __forceinline__ void sincos64(double x, double& s, double& c) { math::sincos_table<false>(x, sincos_lds(), s, c); }
+  static __device__ __forceinline__ void sincos(float x, float& s, float& c) {
+    double sd, cd;
+    sincos64((double)x, sd, cd);
+    s = (float)sd;
+    c = (float)cd;
+  }
+  static __device__ __forceinline__ float cos(float x) {
+    double sd, cd;
+    sincos64((double)x, sd, cd);
+    return (float)cd;
+  }
+  // (float)Math.Cos(x - Math.PI / 2.0) with x a float: the subtraction is in double
+  static __device__ __forceinline__ float cos_minus_half_pi(float x) {
+    double sd, cd;
+    sincos64((double)x - M_PI / 2.0, sd, cd);
+    return (float)cd;
+  }
+  static __device__ __forceinline__ float atan2(float y, float x) { return (float)math::atan2_f64((double)y, (double)x); }
+};
+
 template <>
 struct Trig<GX_MODE_EXACT, false> {
   // |x| <= pi/4 promised only by the BOUNDED variant; here any float

@@ -4,6 +4,8 @@
 //   sincos_small: (float)sin / (float)cos of every `stride`-th float in
 //                 [-pi/4, pi/4] against (float)sin((double)x), (float)cos(...)
 //   sincos_bounded: floats in [-16, 16] and their shifts by -pi/2 and +pi, the same way
+//   sincos_table:   the same arguments (with and without the tail of the reduced argument), and its
+//                   binary64 error off the float grid
 //   atan2_f64: random float pairs against (float)atan2((double)y, (double)x), and in binary64
 //   atan2_of_rounded_sincos: floats in [-16, 16] against (float)atan2 of the rounded sine and cosine
 //   div_by_rcp: floats over every divisor of [2.5, 4.5] and [0.5, 1.25] against a / b
@@ -18,6 +20,7 @@
 
 #include "../gym_amd/csrc/gx_math.h"
 
+static const gx::math::SinCosEntry kSinCosTable[GX_SINCOS_TABLE_ENTRIES] = GX_SINCOS_TABLE_VALUES;
 static float from_bits(uint32_t b) { float f; std::memcpy(&f, &b, 4); return f; }
 static uint32_t to_bits(float f) { uint32_t b; std::memcpy(&b, &f, 4); return b; }
 
@@ -55,6 +58,36 @@ int main(int argc, char** argv) {
       }
     }
   std::printf("sincos_bounded: %llu results, mismatches %llu\n", nb, bad_b);
+  // ---- sincos_table: the same arguments, against the same libm results
+  unsigned long long nt = 0, bad_t = 0, bad_tt = 0;
+  for (uint32_t sign = 0; sign < 2; sign++)
+    for (uint32_t b = 0; b <= hi16; b += stride * 3 + 1) {
+      const float x = from_bits(b | (sign << 31));
+      const double args[3] = {(double)x, (double)x - M_PI / 2.0, (double)x + M_PI};
+      for (int k = 0; k < 3; k++) {
+        double s, c;
+        const float rs = (float)std::sin(args[k]), rc = (float)std::cos(args[k]);
+        gx::math::sincos_table<false>(args[k], kSinCosTable, s, c);
+        nt += 2;
+        bad_t += (to_bits((float)s) != to_bits(rs)) + (to_bits((float)c) != to_bits(rc));
+        gx::math::sincos_table<true>(args[k], kSinCosTable, s, c);
+        bad_tt += (to_bits((float)s) != to_bits(rs)) + (to_bits((float)c) != to_bits(rc));
+      }
+    }
+  std::printf("sincos_table: %llu results, mismatches %llu (%llu with the tail)\n", nt, bad_t, bad_tt);
+  // its accuracy in binary64 itself, off the float grid, |x| <= 16
+  double worst_tab = 0.0;
+  for (uint32_t sign = 0; sign < 2; sign++)
+    for (uint32_t b = 0; b <= hi16; b += stride * 5 + 3) {
+      const double x = (double)from_bits(b | (sign << 31)) * 1.0000000123;
+      double s, c;
+      gx::math::sincos_table<false>(x, kSinCosTable, s, c);
+      const double rs = std::sin(x), rc = std::cos(x);
+      const double es = std::fabs(s - rs) / std::fmax(std::fabs(rs), 0x1.0p-20);
+      const double ec = std::fabs(c - rc) / std::fmax(std::fabs(rc), 0x1.0p-20);
+      worst_tab = std::fmax(worst_tab, std::fmax(es, ec));
+    }
+  std::printf("sincos_table: worst relative error in binary64 %.3g\n", worst_tab);
   // ---- sincos_reduced: binary64 accuracy itself, |x| <= 16, against libm
   double worst = 0.0;
   for (uint32_t sign = 0; sign < 2; sign++)
@@ -129,15 +162,19 @@ int main(int argc, char** argv) {
   for (uint32_t sign = 0; sign < 2; sign++)
     for (uint32_t b = 0; b <= hi16; b += stride / 4 + 1) {
       const float th = from_bits(b | (sign << 31));
-      double S, C;
-      gx::math::sincos_bounded((double)th, S, C);
-      const float s = (float)S, c = (float)C;
-      const float got = gx::math::atan2_of_rounded_sincos(th, S, C, s, c);
-      const float ref = (float)std::atan2((double)s, (double)c);
-      nr++;
-      if (to_bits(got) != to_bits(ref)) {
-        bad_r++;
-        if (bad_r <= 5) std::printf("atan2_of_rounded_sincos(%.9g): %.9g, libm %.9g\n", th, got, ref);
+      // with the sine and cosine of either routine the kernels take them from
+      for (int which = 0; which < 2; which++) {
+        double S, C;
+        if (which == 0) gx::math::sincos_bounded((double)th, S, C);
+        else gx::math::sincos_table<false>((double)th, kSinCosTable, S, C);
+        const float s = (float)S, c = (float)C;
+        const float got = gx::math::atan2_of_rounded_sincos(th, S, C, s, c);
+        const float ref = (float)std::atan2((double)s, (double)c);
+        nr++;
+        if (to_bits(got) != to_bits(ref)) {
+          bad_r++;
+          if (bad_r <= 5) std::printf("atan2_of_rounded_sincos(%.9g): %.9g, libm %.9g\n", th, got, ref);
+        }
       }
     }
   std::printf("atan2_of_rounded_sincos: %llu angles, mismatches %llu\n", nr, bad_r);
@@ -183,6 +220,6 @@ int main(int argc, char** argv) {
     }
   std::printf("div_by_total_mass: %llu inputs, mismatches %llu\n", nd, bad_d);
   // one rounding-boundary event per ~2^28 trig calls is expected; the division must be exact
-  const bool ok = special_ok && bad_r * (1ull << 23) <= nr + (1ull << 23) && worst_ulp <= 2.0 && bad_a * (1ull << 23) <= na + (1ull << 23) && worst < 1e-15 && worst_f < 3e-7 && worst_at < 6e-7 && bad_d == 0 && bad_q == 0 && bad_b * (1ull << 24) <= nb + (1ull << 24) && bad_s * (1ull << 24) <= n + (1ull << 24) && bad_c * (1ull << 24) <= n + (1ull << 24);
+  const bool ok = special_ok && bad_r * (1ull << 23) <= nr + (1ull << 23) && worst_ulp <= 2.0 && bad_a * (1ull << 23) <= na + (1ull << 23) && worst < 1e-15 && worst_f < 3e-7 && worst_at < 6e-7 && bad_d == 0 && bad_q == 0 && bad_b * (1ull << 24) <= nb + (1ull << 24) && bad_t * (1ull << 24) <= nt + (1ull << 24) && bad_tt * (1ull << 24) <= nt + (1ull << 24) && worst_tab < 4e-16 && bad_s * (1ull << 24) <= n + (1ull << 24) && bad_c * (1ull << 24) <= n + (1ull << 24);
   return ok ? 0 : 1;
 }
