@@ -186,6 +186,10 @@ struct AcrobotAngles {
   static constexpr bool kRecomputeAddresses = true;
   static constexpr bool kStateInLds = GX_ACROBOT_ANGLES_LDS != 0;
   static constexpr int kMinWaves = GX_ACROBOT_ANGLES_WAVES;  // resident waves per SIMD the fused kernels are compiled for
+  // The fused rollouts are arithmetic from end to end: three waves with the states in registers beat four with the
+  // states in LDS there (K = 64 at 16 Mi envs: 8.20 against 8.65 ms), while the single step, which waits on memory
+  // as well, wants the waves (0.205 against 0.213 ms).
+  static constexpr int kMinWavesRollout = 3;
   using Real = float;
   static constexpr int W = GX_ACROBOT_W;
   static constexpr bool kDerivedObs = false;

@@ -40,6 +40,9 @@ struct Acrobot64 {
   // every sin/cos argument of an RK4 stage stays below 16 for any finite state
   static constexpr bool kAlwaysBounded = true;
   static constexpr int kStepReturn = -1;  // reward -1 on every step but the final one
+#ifdef GX_ACROBOT64_WAVES  // A/B builds only: resident waves per SIMD the fused kernels are compiled for
+  static constexpr int kMinWaves = GX_ACROBOT64_WAVES;
+#endif
 #ifdef GX_ACROBOT_NO_TABLE  // A/B builds only: the polynomial routine with quadrant selection
   static constexpr bool kSinCosTable = false;
   static __device__ __forceinline__ void sincos(double x, double& s, double& c) { math::sincos_reduced(x, s, c); }
@@ -99,9 +102,13 @@ struct Acrobot64 {
   // itself produces; anything still outside (a stage slope beyond the velocity bounds, a huge angle
   // written by a caller) is reduced in one multiply-add, and a non-finite value ends as NaN instead of
   // keeping a loop alive.
-  static __device__ __forceinline__ double wrap_pi(double x) {
+  static __device__ __forceinline__ double wrap_turn(double x) {
     const double two_pi = 2.0 * M_PI;
     if (fabs(x) > M_PI) x -= copysign(two_pi, x);
+    return x;
+  }
+  static __device__ __forceinline__ double wrap_far(double x) {
+    const double two_pi = 2.0 * M_PI;
     if (!(fabs(x) <= M_PI)) x = fma(-two_pi, rint(x * (1.0 / two_pi)), x);
     return x;
   }
@@ -127,8 +134,19 @@ struct Acrobot64 {
       sum = fma(2.0, k3[i], sum) + k4[i];
       y[i] = fma(dt / 6.0, sum, s[i]);
     }
-    y[0] = wrap_pi(y[0]);
-    y[1] = wrap_pi(y[1]);
+    y[0] = wrap_turn(y[0]);
+    y[1] = wrap_turn(y[1]);
+#ifdef GX_ACROBOT64_WRAP_ALWAYS  // A/B builds only
+    y[0] = wrap_far(y[0]);
+    y[1] = wrap_far(y[1]);
+#else
+    // what one turn did not bring home is rare enough (never, for states the env itself produced at ordinary
+    // accelerations) that the whole wave skips the general reduction unless one of its lanes needs it
+    if (__any(!(fabs(y[0]) <= M_PI) || !(fabs(y[1]) <= M_PI))) {
+      y[0] = wrap_far(y[0]);
+      y[1] = wrap_far(y[1]);
+    }
+#endif
     const double mv1 = 4.0 * M_PI, mv2 = 9.0 * M_PI;
     y[2] = y[2] < -mv1 ? -mv1 : (y[2] > mv1 ? mv1 : y[2]);
     y[3] = y[3] < -mv2 ? -mv2 : (y[3] > mv2 ? mv2 : y[3]);

@@ -181,7 +181,22 @@ struct MountainCarContinuous {
   static __device__ __forceinline__ Act sample(uint32_t w) { return box_sample(word_uniform(w), -1.0f, 1.0f); }
 };
 
+#ifdef GX_PENDULUM_TABLE  // A/B builds: Pendulum's EXACT sin/cos through the LDS table
+template <int MODE>
+struct PendulumTrigOf { using type = Trig<MODE, true>; };
+template <>
+struct PendulumTrigOf<GX_MODE_EXACT> { using type = TrigTable; };
+template <int MODE>
+using PendulumTrig = typename PendulumTrigOf<MODE>::type;
+constexpr bool kPendulumSinCosTable = true;
+#else
+template <int MODE>
+using PendulumTrig = Trig<MODE, true>;
+constexpr bool kPendulumSinCosTable = false;
+#endif
+
 struct Pendulum {
+  static constexpr bool kSinCosTable = kPendulumSinCosTable;
   static constexpr int NS = 3;
   using Real = float;
   static constexpr int W = 4;
@@ -203,7 +218,7 @@ struct Pendulum {
     Draws d0 = philox_block(key, env, 0, 0);
     float theta = (float)(d0.uniform(0) * 2 * M_PI - M_PI);
     float thetaDot = (float)(d0.uniform(1) * 1 - 0.5);
-    Trig<GX_MODE_EXACT, true>::sincos(theta, s[1], s[0]);
+    PendulumTrig<GX_MODE_EXACT>::sincos(theta, s[1], s[0]);
     s[2] = thetaDot;
   }
 
@@ -217,16 +232,17 @@ struct Pendulum {
     const float m = 1.0f;
     const float l = 1.0f;
 
-    float theta = Trig<MODE, BOUNDED>::atan2(s[1], s[0]);
+    using T = PendulumTrig<MODE>;
+    float theta = T::atan2(s[1], s[0]);
     float thetaDot = s[2];
     float u = clampf(action, -max_torque, max_torque);
 
     float new_thetaDot =
-        thetaDot + (-3 * g / (2 * l) * Trig<MODE, BOUNDED>::sin_plus_pi(theta) + 3.0f / (m * l * l) * u) * dt;
+        thetaDot + (-3 * g / (2 * l) * T::sin_plus_pi(theta) + 3.0f / (m * l * l) * u) * dt;
     new_thetaDot = clampf(new_thetaDot, -max_speed, max_speed);
     float new_theta = theta + new_thetaDot * dt;
 
-    Trig<MODE, BOUNDED>::sincos(new_theta, s[1], s[0]);
+    T::sincos(new_theta, s[1], s[0]);
     s[2] = new_thetaDot;
     steps++;
 

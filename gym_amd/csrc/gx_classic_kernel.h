@@ -204,6 +204,19 @@ struct MinWaves<E, std::void_t<decltype(E::kMinWaves)>> {
   static constexpr int value = E::kMinWaves;
 };
 
+// E::kMinWavesRollout: the same for the CACHED form (fused rollouts with the in-kernel policy); with it an env that
+// parks its states in LDS keeps them in registers in that form (E::kStateInLds then holds for the other forms only).
+template <class E, class = void>
+struct MinWavesRollout {
+  static constexpr int value = MinWaves<E>::value;
+  static constexpr bool unpark = false;
+};
+template <class E>
+struct MinWavesRollout<E, std::void_t<decltype(E::kMinWavesRollout)>> {
+  static constexpr int value = E::kMinWavesRollout;
+  static constexpr bool unpark = true;
+};
+
 // CACHED (fused K-step rollouts with the random policy): the policy block of four ticks is kept
 // in registers, so the generator runs once every four steps; the single-step kernels draw
 // the block and use one word of it (16 registers per lane fewer, one more resident wave).
@@ -212,7 +225,7 @@ struct MinWaves<E, std::void_t<decltype(E::kMinWaves)>> {
 // the plain kernels registers (the scalar file is full: they spill into vector registers) and with
 // them a resident wave.
 template <class E, int MODE, int POLICY, bool FUSED, bool BOUNDED, bool CACHED = false, bool ROWS = false>
-__global__ void __launch_bounds__(kClassicBlock, (FUSED && BOUNDED) ? MinWaves<E>::value : 1) classic_step_kernel(StepArgs a) {
+__global__ void __launch_bounds__(kClassicBlock, (FUSED && BOUNDED) ? (CACHED ? MinWavesRollout<E>::value : MinWaves<E>::value) : 1) classic_step_kernel(StepArgs a) {
   using Real = typename E::Real;
   using Act = typename E::Act;
   using Rew = typename E::Rew;
@@ -221,7 +234,7 @@ __global__ void __launch_bounds__(kClassicBlock, (FUSED && BOUNDED) ? MinWaves<E
   constexpr int NR = RegState<E>::value;
   constexpr int W = E::W;
   constexpr int WO = WriteOnlyRows<E>::value;
-  constexpr bool PARK = StateInLds<E>::value;
+  constexpr bool PARK = StateInLds<E>::value && !(CACHED && MinWavesRollout<E>::unpark);
   static_assert(!PARK || (NR == NS && !E::kDerivedObs), "the LDS form holds the stored rows only");
   __shared__ Real parked[PARK ? NS : 1][W][kClassicBlock];
   const int lane = threadIdx.x;

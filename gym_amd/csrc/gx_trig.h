@@ -63,6 +63,12 @@ struct TrigTable {
     sincos64((double)x - M_PI / 2.0, sd, cd);
     return (float)cd;
   }
+  // (float)Math.Sin(x + Math.PI)
+  static __device__ __forceinline__ float sin_plus_pi(float x) {
+    double sd, cd;
+    sincos64((double)x + M_PI, sd, cd);
+    return (float)sd;
+  }
   static __device__ __forceinline__ float atan2(float y, float x) { return (float)math::atan2_f64((double)y, (double)x); }
 };
 
