@@ -136,10 +136,11 @@ B_ALG = {
     "pong": 60 + 60 + 4 + 4 + 4 + 4 + 1 + 100800,          # 100937
     "breakout": 72 + 72 + 4 + 4 + 4 + 4 + 1 + 100800,      # 100961
     "spaceinvaders": 140 + 140 + 4 + 4 + 4 + 4 + 1 + 100800,  # 101097
-    # observation index r+w, steps r+w, ep_return r+w, reward, done.  The reference's Step ignores its action
-    # (Envs.Blackjack.cs:35-37) and so does the kernel: the action row is never read (FETCH_SIZE agrees: 12 B per
-    # env).  --blackjack-full (upstream's rules) adds the action and the face-down row r+w.
-    "blackjack": 4 + 4 + 4 + 4 + 4 + 4 + 4 + 1,           # 29
+    # observation index r+w, steps r+w, reward, done.  The reference's Step ignores its action
+    # (Envs.Blackjack.cs:35-37) and so does the kernel: the action row is never read.  A reward other than 0 ends
+    # the episode under either rule set, so the open-episode return is always 0 and its row is never moved.
+    # --blackjack-full (upstream's rules) adds the action and the face-down row r+w.
+    "blackjack": 4 + 4 + 4 + 4 + 4 + 1,                   # 21
 }
 # binary64 mode: the state rows double in width (read + write), nothing else changes
 B_ALG_FP64_EXTRA = {"cartpole": 32, "mountaincar": 16, "mountaincarcontinuous": 16, "pendulum": 24, "acrobot": 48}

@@ -95,10 +95,10 @@ __global__ void __launch_bounds__(kBlock) blackjack_step_kernel(StepArgs a) {
     load4i(obs_row, q, obs);
     if (FULL) load4i(hidden_row, q, hidden);
     load4i(steps_row, q, steps);
-    if (record) {
-      load4i(static_cast<const int32_t*>(a.ep_return), q, ep_ret);
-      if (a.ep_length) load4i(a.ep_length, q, ep_len);
-    }
+    // Under either rule set a reward other than 0 comes with done (Envs.Blackjack.cs:36-37: 1 at the tenth step;
+    // upstream: a bust or the settled hand), so the return of an open episode is 0 at every step boundary: the
+    // ep_return row holds zeros from its allocation on and is neither read nor written (8 bytes per env-step).
+    if (record && a.ep_length) load4i(a.ep_length, q, ep_len);
     float reward[4];
     bool done[4], trunc[4];
     // the env's word of the tick gives the random policy its action and a hit its card
@@ -205,10 +205,7 @@ __global__ void __launch_bounds__(kBlock) blackjack_step_kernel(StepArgs a) {
     if (FULL || autoreset) store4i(obs_row, q, obs);
     if (FULL) store4i(hidden_row, q, hidden);
     store4i(steps_row, q, steps);
-    if (record) {
-      store4i(static_cast<int32_t*>(a.ep_return), q, ep_ret);
-      if (a.ep_length) store4i(a.ep_length, q, ep_len);
-    }
+    if (record && a.ep_length) store4i(a.ep_length, q, ep_len);
     if (!a.skip_last) {  // write-only rows stream past the caches
       store4f_nt(static_cast<float*>(a.reward), q, reward);
       __builtin_nontemporal_store(pack4(done), reinterpret_cast<uint32_t*>(a.done) + q);
