@@ -97,3 +97,27 @@ def test_device_math_header_against_libm(tmp_path):
     out = subprocess.run([exe, "257"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "div_by_total_mass" in out.stdout and "mismatches 0" in out.stdout.splitlines()[-1]
+
+
+def test_header_is_plain_c_and_struct_sizes_hold(tmp_path):
+    """include/gymx.h is a C header (what a cgo / P/Invoke / ctypes author reads): it compiles as strict C99 on its
+    own, and the sizes and offsets the bindings mirror are what the compiler lays out"""
+    src = tmp_path / "abi.c"
+    src.write_text("""
+#include <stddef.h>
+#include "gymx.h"
+#define SA(c, n) typedef char static_assert_##n[(c) ? 1 : -1]
+SA(sizeof(gx_desc) == 96, desc);
+SA(offsetof(gx_desc, table) == GX_DESC_SIZE_V1, desc_v1);
+SA(offsetof(gx_desc, map_rows) == 48, desc_map);
+SA(sizeof(gx_transition) == 12, transition);
+SA(sizeof(gx_info) == 72, info);
+SA(sizeof(gx_view) == 64, view);
+SA(sizeof(gx_stats) == 48, stats);
+SA(sizeof(gx_rows) == %d, rows);
+SA(GX_ENV_COUNT == 14 && GX_ENV_TABLE == 13, envs);
+int main(void) { gx_desc d = {0}; d.struct_size = (uint32_t)sizeof d; return (int)d.struct_size - 96; }
+""" % C.sizeof(L.GxRows))
+    exe = str(tmp_path / "abi")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"), str(src), "-o", exe])
+    assert subprocess.run([exe]).returncode == 0
