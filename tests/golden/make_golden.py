@@ -52,7 +52,21 @@ CASES = [
     ("taxi", O.TAXI, 6, {}), ("cliffwalking", O.CLIFFWALKING, 4, {}), ("pong", O.PONG, 4, {}),
     ("breakout", O.BREAKOUT, 4, {}),
     ("spaceinvaders", O.SPACEINVADERS, 6, {}),
+    # an env stepped from a caller-supplied table (include/gymx.h GX_ENV_TABLE): 300 states x 5 actions x 3 equally
+    # likely outcomes, twelve distinct rewards, Reset() to a uniform draw, the env's own limit of 40 steps; the table
+    # itself is part of the fixture
+    ("table_random", O.TABLE, 5, {"flags": O.AUTORESET, "table": "random", "n_outcomes": 3, "start_state": -1, "step_limit": 40}),
 ]
+
+
+def random_table(rng, n_states, n_actions, n_outcomes):
+    t = np.zeros((n_states, n_actions, n_outcomes), O.TRANSITION_DTYPE)
+    t["next_state"] = rng.integers(0, n_states, t.shape)
+    t["reward"] = rng.choice(np.array([-3, -1, 0, 1, 2, 7, 10, -20, 50, 4, 5, 6], np.float32), t.shape)
+    t["done"] = rng.random(t.shape) < 0.05
+    return t
+
+
 CASES_FP64 = [("cartpole_fp64", O.CARTPOLE, 2), ("mountaincar_fp64", O.MOUNTAINCAR, 3), ("mountaincar_cont_fp64", O.MOUNTAINCAR_CONT, None),
               ("pendulum_fp64", O.PENDULUM, None), ("acrobot_fp64", O.ACROBOT, 3)]
 
@@ -61,6 +75,10 @@ def main():
     for name, eid, nact, kw in CASES:
         rng = np.random.default_rng(sum(map(ord, name)))
         steps = {"pong": 400, "breakout": 600, "spaceinvaders": 900}.get(name, T)
+        kw = dict(kw)
+        table = None
+        if kw.get("table") == "random":
+            table = kw["table"] = random_table(rng, 300, nact, kw["n_outcomes"])
         v = O.OracleVec(eid, N, seed=SEED, **kw)
         v.reset()
         init = v.get_state_raw().copy()
@@ -84,6 +102,9 @@ def main():
             out["map_rows"] = np.array("/".join(kw["map_rows"]))
         if kw.get("flags"):
             out["flags"] = np.int64(kw["flags"])
+        if table is not None:
+            out.update(table_next_state=table["next_state"], table_reward=table["reward"], table_done=table["done"],
+                       start_state=np.int64(kw["start_state"]), step_limit=np.int64(kw["step_limit"]))
         if frames:
             out["frame_index" if name in ("breakout", "spaceinvaders") else "frame_masks"] = np.stack(frames)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)

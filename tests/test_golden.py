@@ -15,9 +15,19 @@ FILES = sorted(glob.glob(os.path.join(HERE, "golden", "*.npz")))
 ENV_OF = {"cartpole": "CARTPOLE", "mountaincar": "MOUNTAINCAR", "mountaincar_cont": "MOUNTAINCAR_CONT", "pendulum": "PENDULUM",
           "acrobot": "ACROBOT", "frozenlake": "FROZENLAKE", "frozenlake_8x8": "FROZENLAKE", "taxi": "TAXI",
           "frozenlake_8x8_slippery": "FROZENLAKE", "taxi_full": "TAXI", "blackjack": "BLACKJACK", "blackjack_full": "BLACKJACK",
-          "cliffwalking": "CLIFFWALKING", "pong": "PONG", "breakout": "BREAKOUT", "spaceinvaders": "SPACEINVADERS"}
+          "cliffwalking": "CLIFFWALKING", "pong": "PONG", "breakout": "BREAKOUT", "spaceinvaders": "SPACEINVADERS",
+          "table_random": "TABLE"}
 EXACT = {"frozenlake", "frozenlake_8x8", "taxi", "cliffwalking", "pong", "breakout", "spaceinvaders", "frozenlake_8x8_slippery", "taxi_full",
-         "blackjack", "blackjack_full"}
+         "blackjack", "blackjack_full", "table_random"}
+
+
+def table_kwargs(z):
+    """the caller-supplied table of a fixture that holds one, as the keyword arguments both engines take"""
+    if "table_next_state" not in z.files:
+        return {}
+    t = np.zeros(z["table_next_state"].shape, [("next_state", np.int32), ("reward", np.float32), ("done", np.int32)])
+    t["next_state"], t["reward"], t["done"] = z["table_next_state"], z["table_reward"], z["table_done"]
+    return dict(table=t, n_outcomes=t.shape[2], start_state=int(z["start_state"]), step_limit=int(z["step_limit"]))
 
 
 def load(path):
@@ -38,7 +48,7 @@ def palette_index(frames):
 
 
 def test_fixtures_present():
-    assert len(FILES) == 21
+    assert len(FILES) == 22
 
 
 @pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f)[:-4] for f in FILES])
@@ -47,7 +57,7 @@ def test_oracle_reproduces_golden(oracle, path):
     n = z["actions"].shape[1]
     fp64 = name.endswith("_fp64")
     v = oracle.OracleVec(getattr(oracle, ENV_OF[name[:-5] if fp64 else name]), n, seed=int(z["seed"]), map_rows=rows,
-                         flags=oracle.FP64 if fp64 else (int(z["flags"]) if "flags" in z.files else 0))
+                         flags=oracle.FP64 if fp64 else (int(z["flags"]) if "flags" in z.files else 0), **table_kwargs(z))
     v.reset()
     assert np.array_equal(v.get_state_raw(), z["init"])
     frames = []
@@ -74,7 +84,7 @@ def test_gpu_reproduces_golden(path):
     if name.endswith("_fp64"):
         return gpu_fp64_golden(name, z, n)
     g = DeviceBatch(ctx(), getattr(L, "ENV_" + ENV_OF[name]), n, seed=int(z["seed"]), map_rows=rows,
-                    flags=int(z["flags"]) if "flags" in z.files else 0)
+                    flags=int(z["flags"]) if "flags" in z.files else 0, **table_kwargs(z))
     g.reset()
     assert np.array_equal(g.get_state_raw(), z["init"])  # Reset() draws are integer / one-rounding work: exact
     frames = []
