@@ -292,3 +292,42 @@ def test_acrobot_rk4_16mi_rollout64(oracle):
     sb = b.stats()
     assert (sb.episodes, sb.sum_length, sb.sum_return) == (s.episodes, s.sum_length, s.sum_return)
     a.close(); b.close()
+
+
+def test_caller_supplied_table_64mi(oracle):
+    """64 Mi envs stepped from a caller-supplied table: upstream's 8x8 slippery FrozenLake written out as P[s][a][o]
+    equals the batch built from the env id and the map, state for state over the whole batch and in its statistics;
+    a window of a random 300 x 5 table equals an oracle batch keyed at the same global env indices"""
+    import torch
+
+    import tables as T
+
+    n = 1 << 26
+    door = DeviceBatch(ctx(), L.ENV_TABLE, n, seed=9, flags=FUSED, table=T.frozenlake(T.MAP8, True), n_outcomes=3, start_state=0, step_limit=100)
+    builtin = DeviceBatch(ctx(), L.ENV_FROZENLAKE, n, seed=9, flags=FUSED | L.SLIPPERY, map_rows="8x8")
+    door.reset(); builtin.reset()
+    door.rollout(16); builtin.rollout(16)
+    for _ in range(24):
+        door.step_random(); builtin.step_random()
+    ctx().synchronize()
+    vd, vb = torch_views(door), torch_views(builtin)
+    assert torch.equal(vd["state_int"][:, :n], vb["state_int"][:, :n])
+    assert torch.equal(vd["reward"][:n], vb["reward"][:n]) and torch.equal(vd["done"][:n], vb["done"][:n])
+    sd, sb = door.stats(), builtin.stats()
+    assert (sd.episodes, sd.sum_length, sd.sum_return) == (sb.episodes, sb.sum_length, sb.sum_return) and sd.episodes > n // 4
+    door.close(); builtin.close()
+
+    table = T.random_table(np.random.default_rng(3), 300, 5, 3)
+    base, width, k = n - 70_000, 4096, 30
+    g = DeviceBatch(ctx(), L.ENV_TABLE, n, seed=4, flags=FUSED, table=table, n_outcomes=3, start_state=-1, step_limit=40)
+    o = oracle.OracleVec(oracle.TABLE, width, seed=4, flags=oracle.AUTORESET, table=table, n_outcomes=3, start_state=-1,
+                         step_limit=40, env_index_base=base)
+    g.reset(); o.reset()
+    for _ in range(k):
+        g.step_random(); o.step_random()
+    ctx().synchronize()
+    v = torch_views(g)
+    assert np.array_equal(v["state_int"][:, base:base + width].cpu().numpy(), o.get_state()[1])
+    st = v["state_int"][0, :n]
+    assert int(st.min()) >= 0 and int(st.max()) < 300 and int(v["state_int"][1, :n].max()) <= 40
+    g.close()
