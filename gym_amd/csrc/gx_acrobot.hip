@@ -190,6 +190,7 @@ struct AcrobotAngles {
   // states in LDS there (K = 64 at 16 Mi envs: 8.20 against 8.65 ms), while the single step, which waits on memory
   // as well, wants the waves (0.205 against 0.213 ms).
   static constexpr int kMinWavesRollout = 3;
+  static constexpr bool kPrefetchNextTrip = true;
   using Real = float;
   static constexpr int W = GX_ACROBOT_W;
   static constexpr bool kDerivedObs = false;

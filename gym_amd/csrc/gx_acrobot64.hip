@@ -24,6 +24,7 @@
 namespace gx {
 
 struct Acrobot64 {
+  static constexpr bool kPrefetchNextTrip = true;
   static constexpr int NS = 4;
   static constexpr int NR = 8;  // + sin(theta1), cos(theta1), sin(theta2), cos(theta2) of the current state
   using Real = double;

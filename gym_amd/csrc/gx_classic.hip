@@ -139,6 +139,7 @@ struct MountainCar {
 };
 
 struct MountainCarContinuous {
+  static constexpr bool kPrefetchNextTrip = true;
   static constexpr int NS = 2;
   using Real = float;
   static constexpr int W = 4;
@@ -196,6 +197,7 @@ constexpr bool kPendulumSinCosTable = false;
 #endif
 
 struct Pendulum {
+  static constexpr bool kPrefetchNextTrip = true;
   static constexpr bool kSinCosTable = kPendulumSinCosTable;
   static constexpr int NS = 3;
   using Real = float;

@@ -151,6 +151,7 @@ struct MountainCar64 {
 };
 
 struct MountainCarContinuous64 {
+  static constexpr bool kPrefetchNextTrip = true;
   static constexpr int NS = 2;
   using Real = double;
   static constexpr int W = 2;

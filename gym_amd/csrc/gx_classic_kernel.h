@@ -191,6 +191,22 @@ struct UsesSinCosTable<E, std::void_t<decltype(E::kSinCosTable)>> {
   static constexpr bool value = E::kSinCosTable;
 };
 
+// E::kPrefetchNextTrip: the single-step kernel with actions read from memory requests the rows of the lane's next
+// trip before the arithmetic of the current one (24 registers more for a four-row env).  The requests then precede
+// the current trip's stores in the wave's memory queue, so the next trip starts as soon as its own rows are there
+// instead of after the stores before them have been acknowledged.  Measured at 16 Mi envs, kernel ms without / with:
+// RK4 Acrobot 0.390 / 0.344, MountainCarContinuous 0.1474 / 0.1426 (binary64 0.1937 / 0.1908), Pendulum 0.1722 /
+// 0.1702, Acrobot EXACT 0.1997 / 0.1976; CartPole and MountainCar lose 1 % and every env's in-kernel-policy form
+// loses 0-4 % (no action row to wait for: their waves are not short of requests in flight), so those keep the plain form.
+template <class E, class = void>
+struct PrefetchNextTrip {
+  static constexpr bool value = false;
+};
+template <class E>
+struct PrefetchNextTrip<E, std::void_t<decltype(E::kPrefetchNextTrip)>> {
+  static constexpr bool value = E::kPrefetchNextTrip;
+};
+
 // minimum resident waves per SIMD the fused kernels are compiled for (caps their registers): E::kMinWaves, else 1
 #ifndef GX_FUSED_MIN_WAVES
 #define GX_FUSED_MIN_WAVES 1
@@ -224,7 +240,8 @@ struct MinWavesRollout<E, std::void_t<decltype(E::kMinWavesRollout)>> {
 // or nothing at all is handed back (skip_last).  A separate variant because the extra pointers cost
 // the plain kernels registers (the scalar file is full: they spill into vector registers) and with
 // them a resident wave.
-template <class E, int MODE, int POLICY, bool FUSED, bool BOUNDED, bool CACHED = false, bool ROWS = false>
+// SINGLE: exactly one step per launch (a.k_steps is 1), known at compile time; the form that requests a trip ahead.
+template <class E, int MODE, int POLICY, bool FUSED, bool BOUNDED, bool CACHED = false, bool ROWS = false, bool SINGLE = false>
 __global__ void __launch_bounds__(kClassicBlock, (FUSED && BOUNDED) ? (CACHED ? MinWavesRollout<E>::value : MinWaves<E>::value) : 1) classic_step_kernel(StepArgs a) {
   using Real = typename E::Real;
   using Act = typename E::Act;
@@ -259,37 +276,87 @@ __global__ void __launch_bounds__(kClassicBlock, (FUSED && BOUNDED) ? (CACHED ? 
   if (kLdsStats && record) lane_stats_init(lane_stats);
 
   const uint64_t ngroups = (a.num_envs + (W - 1)) / W;
-  for (uint64_t it = (uint64_t)blockIdx.x * kClassicBlock + threadIdx.x; it < ngroups; it += (uint64_t)gridDim.x * kClassicBlock) {
-    // consecutive launches sweep the batch in opposite directions: the rows a sweep touched
-    // last are still in the 256 MiB memory-side cache when the next sweep starts there
-    const uint64_t q = a.reverse ? ngroups - 1 - it : it;
+  const uint64_t it_stride = (uint64_t)gridDim.x * kClassicBlock;
+  // consecutive launches sweep the batch in opposite directions: the rows a sweep touched
+  // last are still in the 256 MiB memory-side cache when the next sweep starts there
+  auto group_of = [&](uint64_t it) { return a.reverse ? ngroups - 1 - it : it; };
+  // PF: what a trip reads (state rows, step counter, the first step's actions), requested one trip ahead
+  constexpr bool PF = PrefetchNextTrip<E>::value && POLICY == GX_POLICY_DEVICE_ACTIONS && FUSED && BOUNDED && !CACHED && !ROWS && SINGLE;
+  static_assert(!SINGLE || PF, "the single-step form exists for the envs that request a trip ahead");
+  Real next_rows[PF ? NS : 1][W];
+  int32_t next_steps[W];
+  Act next_act[W];
+  auto request = [&](uint64_t g) {
+#pragma unroll
+    for (int c = WO; c < (PF ? NS : 0); c++) load_row<Real, W>(sreal + (uint64_t)c * a.stride, g, next_rows[PF ? c : 0]);
+    load_row<int32_t, W>(steps_row, g, next_steps);
+    if (POLICY == GX_POLICY_DEVICE_ACTIONS) load_row<Act, W>(static_cast<const Act*>(a.actions), g, next_act);
+  };
+  const uint64_t it_first = (uint64_t)blockIdx.x * kClassicBlock + threadIdx.x;
+  if constexpr (PF) {
+    if (it_first < ngroups) request(group_of(it_first));
+    // The first trip's rows are awaited here, outside the sweep: a wait at the loop's head would be counted for
+    // this entry as well as for the back edge, where the stores of the trip before are still in flight behind the
+    // rows, and would wait for those too.
+#pragma unroll
+    for (int j = 0; j < W; j++) {
+#pragma unroll
+      for (int c = WO; c < NS; c++) asm volatile("" : "+v"(next_rows[c][j]));
+      asm volatile("" : "+v"(next_steps[j]));
+      if (POLICY == GX_POLICY_DEVICE_ACTIONS) asm volatile("" : "+v"(next_act[j]));
+    }
+  }
+  for (uint64_t it = it_first; it < ngroups; it += it_stride) {
+    const uint64_t q = group_of(it);
     Real s[W][NR];
     int32_t steps[W];
+    Act first_act[W];
     EpRet ep_ret[W] = {};
     int32_t ep_len[W] = {};
+    if constexpr (PF) {
 #pragma unroll
-    for (int c = 0; c < NS; c++) {
-      Real v[W] = {};
-      if (c >= WO) load_row<Real, W>(sreal + (uint64_t)c * a.stride, q, v);
+      for (int c = WO; c < NS; c++) {
 #pragma unroll
-      for (int j = 0; j < W; j++) {
-        if constexpr (PARK) {
-          if (c >= WO) parked[c][j][lane] = v[j];
-        } else {
-          s[j][c] = v[j];
+        for (int j = 0; j < W; j++) {
+          if constexpr (PARK) parked[c][j][lane] = next_rows[c][j];
+          else s[j][c] = next_rows[c][j];
         }
       }
+#pragma unroll
+      for (int j = 0; j < W; j++) {
+        steps[j] = next_steps[j];
+        first_act[j] = next_act[j];
+      }
+      // what the trip reads besides: before the requests, so that waiting for it does not wait for them
+      if (!derive_returns) load_row<EpRet, W>(static_cast<const EpRet*>(a.ep_return), q, ep_ret);
+      // A lane without a further trip asks for group 0 and drops what comes: with the requests under a branch the
+      // values of the two paths are merged by register copies behind them, which wait for the rows on the spot.
+      request(it + it_stride < ngroups ? group_of(it + it_stride) : 0);
+    } else {
+#pragma unroll
+      for (int c = 0; c < NS; c++) {
+        Real v[W] = {};
+        if (c >= WO) load_row<Real, W>(sreal + (uint64_t)c * a.stride, q, v);
+#pragma unroll
+        for (int j = 0; j < W; j++) {
+          if constexpr (PARK) {
+            if (c >= WO) parked[c][j][lane] = v[j];
+          } else {
+            s[j][c] = v[j];
+          }
+        }
+      }
+      load_row<int32_t, W>(steps_row, q, steps);
     }
     if constexpr (NR > NS) {
 #pragma unroll
       for (int j = 0; j < W; j++) E::derive(s[j]);
     }
-    load_row<int32_t, W>(steps_row, q, steps);
     if (record) {
       if (derive_returns) {
 #pragma unroll
         for (int j = 0; j < W; j++) ep_ret[j] = (EpRet)(E::kStepReturn * steps[j]);
-      } else {
+      } else if (!PF) {
         load_row<EpRet, W>(static_cast<const EpRet*>(a.ep_return), q, ep_ret);
       }
       if (ep_length_row) load_row<int32_t, W>(ep_length_row, q, ep_len);
@@ -299,12 +366,19 @@ __global__ void __launch_bounds__(kClassicBlock, (FUSED && BOUNDED) ? (CACHED ? 
     bool done[W], trunc[W];
     Draws policy[CACHED ? W : 1];
     const uint64_t env0 = a.env_index_base + q * W;
-    for (int k = 0; k < a.k_steps; k++) {
+    const int k_steps = SINGLE ? 1 : a.k_steps;
+    for (int k = 0; k < k_steps; k++) {
       const uint64_t tick = a.tick + (uint64_t)k;
       const RngKey key = make_key(a.seed_lo, a.seed_hi, tick);
       Act act[W];
-      if (POLICY == GX_POLICY_DEVICE_ACTIONS)
-        load_row<Act, W>(static_cast<const Act*>(a.actions) + (uint64_t)k * a.action_stride, q, act);
+      if (POLICY == GX_POLICY_DEVICE_ACTIONS) {
+        if (PF && k == 0) {
+#pragma unroll
+          for (int j = 0; j < W; j++) act[j] = first_act[j];
+        } else {
+          load_row<Act, W>(static_cast<const Act*>(a.actions) + (uint64_t)k * a.action_stride, q, act);
+        }
+      }
       if (CACHED && POLICY == GX_POLICY_RANDOM && (k == 0 || (tick & 3) == 0)) {
 #pragma unroll
         for (int j = 0; j < W; j++) policy[CACHED ? j : 0] = policy_block(a.seed_lo, a.seed_hi, tick, env0 + j);
@@ -541,6 +615,12 @@ static void launch_step_variant(const StepArgs& a, bool fused, bool bounded, dim
   } else if (fused && bounded && kRandom && a.k_steps > 1) {
     hipLaunchKernelGGL((classic_step_kernel<E, MODE, POLICY, true, true, kRandom>), grid, dim3(kClassicBlock), 0, stream, a);
   } else if (fused && bounded) {
+    if constexpr (PrefetchNextTrip<E>::value && POLICY == GX_POLICY_DEVICE_ACTIONS) {
+      if (a.k_steps == 1) {
+        hipLaunchKernelGGL((classic_step_kernel<E, MODE, POLICY, true, true, false, false, true>), grid, dim3(kClassicBlock), 0, stream, a);
+        return;
+      }
+    }
     hipLaunchKernelGGL((classic_step_kernel<E, MODE, POLICY, true, true>), grid, dim3(kClassicBlock), 0, stream, a);
   } else if constexpr (E::kAlwaysBounded) {
     hipLaunchKernelGGL((classic_step_kernel<E, MODE, POLICY, false, true>), grid, dim3(kClassicBlock), 0, stream, a);
