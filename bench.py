@@ -662,7 +662,39 @@ def extra_measurements(ctx, n, stream_ptr, dist, rank, world, scale=1.0):
         m("taxi_v3_full_64Mi_" + tag, "taxi", big, policy=policy, flags_extra=L.TAXI_FULL)
     # Pong: game step + 210x160x3 frame raster per env-step
     m("pong_step_and_raster", "pong", envs(65536), settle=20)
+    res["cartpole_1024_host_path"] = measure_host_path(ctx, 1024)
     return res
+
+
+def measure_host_path(ctx, n, steps=2000, warmup=200):
+    """The reference's own CPU-runnable configuration (CartPole, N = 1024, random actions from the host, auto-reset)
+    through the host path of the boundary: gx_vec_step_async + gx_vec_wait per step with pinned buffers -- actions over
+    PCIe in, observation, reward and done out.  Wall clock on this rank, so the rate includes the copies and the
+    launch: at this size a step is latency, not bandwidth."""
+    import ctypes as C
+
+    b = DeviceBatch(ctx, L.ENV_CARTPOLE, n, seed=1, flags=L.AUTORESET | L.RECORD_STATS)
+    b.reset()
+    lib = L.load()
+    act = torch.randint(0, 2, (n,), dtype=torch.int32).pin_memory()
+    rew = torch.empty(n, dtype=torch.float32).pin_memory()
+    done = torch.empty(n, dtype=torch.uint8).pin_memory()
+    obs = torch.empty((4, n), dtype=torch.float32).pin_memory()
+    vp = lambda t: C.c_void_p(t.data_ptr())
+
+    def step():
+        L.check(lib.gx_vec_step_async(b._h, vp(act), vp(obs), vp(rew), vp(done), None))
+        L.check(lib.gx_vec_wait(b._h))
+
+    for _ in range(warmup):
+        step()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = (time.perf_counter() - t0) / steps
+    b.close()
+    return {"envs": n, "steps": steps, "us_per_step": dt * 1e6, "env_steps_per_s": n / dt,
+            "includes": "PCIe copies of actions in and observation, reward, done out; launch and wait per step"}
 
 
 if __name__ == "__main__":

@@ -154,3 +154,5 @@ def test_extra_carries_every_named_configuration():
     assert ex["taxi_v3_full_64Mi_device_actions"]["bytes_per_env_step"] == 33
     assert ex["taxi_stub_64Mi_device_actions"]["envs_per_gpu"] == 65536
     assert ex["pong_step_and_raster"]["bytes_per_env_step"] == 100937 and ex["pong_step_and_raster"]["envs_per_gpu"] == 4096
+    host = ex["cartpole_1024_host_path"]  # the reference's own CPU-runnable configuration through the host path
+    assert host["envs"] == 1024 and host["us_per_step"] > 0 and abs(host["env_steps_per_s"] - 1024 / (host["us_per_step"] * 1e-6)) < 1.0
