@@ -1,5 +1,5 @@
 """The single-step kernels that request a lane's next trip ahead (MountainCarContinuous, Pendulum, Acrobot in EXACT
-mode, MountainCarContinuous in binary64, RK4 Acrobot; actions read from memory): with a grid of three workgroups
+mode, MountainCarContinuous in binary64, RK4 Acrobot, Blackjack under upstream's rules; actions read from memory): with a grid of three workgroups
 every lane makes several trips, the last of them with nothing left to request, and the batch ends in a ragged lane.
 The results must not depend on the grid, and must be the oracle's."""
 import numpy as np
@@ -73,3 +73,23 @@ def test_trips_requested_ahead_do_not_depend_on_the_grid(oracle, monkeypatch, na
     assert (sf.episodes, sf.sum_length) == (sm.episodes, sm.sum_length) == (so.episodes, so.sum_length)
     assert so.episodes > 0 or env_id == L.ENV_PENDULUM or not written
     assert abs(sf.sum_return - so.sum_return) <= 1e-9 * max(1.0, abs(so.sum_return))
+
+
+def test_blackjack_upstream_rules_requested_ahead(oracle, monkeypatch):
+    n, steps = 20011, 60  # three workgroups of 256 lanes, four envs per lane: seven trips, the last one ragged
+    flags = L.AUTORESET | L.RECORD_STATS | L.BLACKJACK_FULL
+    monkeypatch.setenv("GYMX_GRID_BLOCKS", "3")
+    few, o = make_pair(oracle, L.ENV_BLACKJACK, n, seed=43, flags=flags)
+    monkeypatch.delenv("GYMX_GRID_BLOCKS")
+    for b in (few, o):
+        b.reset()
+    rng = np.random.default_rng(9)
+    for t in range(steps):
+        a = random_actions(rng, L.ENV_BLACKJACK, n)
+        _, rew, done, _ = few.step_host(a)
+        orew, odone, _ = o.step(a)
+        _, fi = few.get_state(); _, oi = o.get_state()
+        assert np.array_equal(fi, oi), t
+        assert np.array_equal(rew.astype(np.float64), orew) and np.array_equal(done, odone), t
+    sf, so = few.stats(), o.stats()
+    assert so.episodes > n and (sf.episodes, sf.sum_length, sf.sum_return) == (so.episodes, so.sum_length, so.sum_return)
