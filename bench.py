@@ -389,6 +389,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    result_line = claim_stdout()
     if os.environ.get("GYMX_BENCH_FAIL_RANK") == str(rank):
         # fault injection for the launcher's test: this rank dies before it joins anything
         print("bench.py: rank %d leaves at start-up (GYMX_BENCH_FAIL_RANK)" % rank, file=sys.stderr)
@@ -577,7 +578,18 @@ def main():
         allc = cpu_baseline_all_cores(args.env)
         if allc:
             out["cpu_baseline_all_cores"] = allc
-    print(json.dumps(out))
+    result_line.write(json.dumps(out) + "\n")
+    result_line.flush()
+
+
+def claim_stdout():
+    """The contract is one JSON line on standard output.  Libraries write there too (gloo announces its connections,
+    RCCL logs there when NCCL_DEBUG is set), so from here on file descriptor 1 is standard error for everybody, native
+    code included, and the result line goes to the descriptor returned, a duplicate of the original standard output."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    return os.fdopen(saved, "w")
 
 
 def measure_single_step(ctx, env, n, stream_ptr, dist, rank, world, policy="device", mode="exact", flags_extra=0,
