@@ -93,7 +93,28 @@ struct CartPole {
   static __device__ __forceinline__ Act sample(uint32_t w) { return word_below(w, NACT); }
 };
 
-struct MountainCar {
+// TABLE: EXACT sin and cos through the LDS table (gx_trig.h).  The two routines round to the same float for every
+// float argument of these envs but one in 3.3 * 10^9 each (tests/host_math_check.cpp walks them all), so which
+// one a kernel uses is a matter of speed only: the table routine is a third shorter, and its table costs every
+// workgroup a 2 KiB fill.  The K = 64 rollouts gain with it (Pendulum 4.90 -> 4.22 ms at 16 Mi envs), the single
+// steps, which wait on memory, lose 0.5-2 % and keep the polynomial routine.
+template <int MODE, bool TABLE>
+struct ClassicTrigOf { using type = Trig<MODE, true>; };
+template <>
+struct ClassicTrigOf<GX_MODE_EXACT, true> { using type = TrigTable; };
+
+// MountainCar's position is unbounded without auto-reset, so the table routine (bounded arguments) serves its
+// BOUNDED EXACT form only.
+template <int MODE, bool BOUNDED, bool TABLE>
+struct CarTrigOf { using type = Trig<MODE, BOUNDED>; };
+template <>
+struct CarTrigOf<GX_MODE_EXACT, true, true> { using type = TrigTable; };
+template <int MODE, bool BOUNDED, bool TABLE>
+using CarTrig = typename CarTrigOf<MODE, BOUNDED, TABLE>::type;
+
+template <bool TABLE>
+struct MountainCarT {
+  static constexpr bool kSinCosTable = TABLE;
   static constexpr int NS = 2;
   using Real = float;
   static constexpr int W = 4;
@@ -123,7 +144,7 @@ struct MountainCar {
   static __device__ __forceinline__ void step(float (&s)[NS], int32_t& steps, Act action, Rew& reward, bool& done) {
     float position = s[0], velocity = s[1];
     float force = (float)(action - 1);
-    velocity += 0.001f * force - 0.0025f * Trig<MODE, BOUNDED>::cos(3 * position);
+    velocity += 0.001f * force - 0.0025f * CarTrig<MODE, BOUNDED, TABLE>::cos(3 * position);
     velocity = clampf(velocity, -0.07f, 0.07f);
     position += velocity;
     if (position < -1.2f) {
@@ -137,8 +158,13 @@ struct MountainCar {
   }
   static __device__ __forceinline__ Act sample(uint32_t w) { return word_below(w, NACT); }
 };
+struct MountainCar : MountainCarT<false> {
+  using Rollout = MountainCarT<true>;
+};
 
-struct MountainCarContinuous {
+template <bool TABLE>
+struct MountainCarContinuousT {
+  static constexpr bool kSinCosTable = TABLE;
   static constexpr bool kPrefetchNextTrip = true;
   static constexpr int NS = 2;
   using Real = float;
@@ -156,7 +182,7 @@ struct MountainCarContinuous {
 
   // Envs.MountainCarContinuous.cs:19-27
   static __device__ __forceinline__ void reset(float (&s)[NS], const RngKey& key, uint64_t env) {
-    MountainCar::reset(s, key, env);
+    MountainCarT<false>::reset(s, key, env);
   }
 
   // Envs.MountainCarContinuous.cs:29-49
@@ -164,7 +190,7 @@ struct MountainCarContinuous {
   static __device__ __forceinline__ void step(float (&s)[NS], int32_t& steps, Act action, Rew& reward, bool& done) {
     float position = s[0], velocity = s[1];
     float force = clampf(action, -1.0f, 1.0f);
-    velocity += force * 0.0015f - 0.0025f * Trig<MODE, BOUNDED>::cos(3 * position);
+    velocity += force * 0.0015f - 0.0025f * CarTrig<MODE, BOUNDED, TABLE>::cos(3 * position);
     velocity = clampf(velocity, -0.07f, 0.07f);
     position += velocity;
     if (position < -1.2f) {
@@ -181,24 +207,16 @@ struct MountainCarContinuous {
   // Box([-1],[1]), Envs.MountainCarContinuous.cs:12
   static __device__ __forceinline__ Act sample(uint32_t w) { return box_sample(word_uniform(w), -1.0f, 1.0f); }
 };
+struct MountainCarContinuous : MountainCarContinuousT<false> {
+  using Rollout = MountainCarContinuousT<true>;
+};
 
-#ifdef GX_PENDULUM_TABLE  // A/B builds: Pendulum's EXACT sin/cos through the LDS table
-template <int MODE>
-struct PendulumTrigOf { using type = Trig<MODE, true>; };
-template <>
-struct PendulumTrigOf<GX_MODE_EXACT> { using type = TrigTable; };
-template <int MODE>
-using PendulumTrig = typename PendulumTrigOf<MODE>::type;
-constexpr bool kPendulumSinCosTable = true;
-#else
-template <int MODE>
-using PendulumTrig = Trig<MODE, true>;
-constexpr bool kPendulumSinCosTable = false;
-#endif
-
-struct Pendulum {
+template <bool TABLE>
+struct PendulumT {
+  template <int MODE>
+  using PendulumTrig = typename ClassicTrigOf<MODE, TABLE>::type;
   static constexpr bool kPrefetchNextTrip = true;
-  static constexpr bool kSinCosTable = kPendulumSinCosTable;
+  static constexpr bool kSinCosTable = TABLE;
   static constexpr int NS = 3;
   using Real = float;
   static constexpr int W = 4;
@@ -220,7 +238,7 @@ struct Pendulum {
     Draws d0 = philox_block(key, env, 0, 0);
     float theta = (float)(d0.uniform(0) * 2 * M_PI - M_PI);
     float thetaDot = (float)(d0.uniform(1) * 1 - 0.5);
-    PendulumTrig<GX_MODE_EXACT>::sincos(theta, s[1], s[0]);
+    Trig<GX_MODE_EXACT, true>::sincos(theta, s[1], s[0]);  // (the polynomial routine in either form: a reset is rare)
     s[2] = thetaDot;
   }
 
@@ -254,6 +272,9 @@ struct Pendulum {
   }
   // Box([-2],[2]), Envs.Pendulum.cs:12
   static __device__ __forceinline__ Act sample(uint32_t w) { return box_sample(word_uniform(w), -2.0f, 2.0f); }
+};
+struct Pendulum : PendulumT<false> {
+  using Rollout = PendulumT<true>;
 };
 
 hipError_t launch_classic_step(int env_id, const StepArgs& a, int mode, int policy, bool fused, bool bounded, dim3 grid,

@@ -207,6 +207,17 @@ struct PrefetchNextTrip<E, std::void_t<decltype(E::kPrefetchNextTrip)>> {
   static constexpr bool value = E::kPrefetchNextTrip;
 };
 
+// E::Rollout: the env as the fused rollouts with the in-kernel policy (the CACHED form) step it -- the same rows and
+// rules with arithmetic routines chosen for a kernel that is bound by instruction issue, not by memory.
+template <class E, bool CACHED, class = void>
+struct StepEnv {
+  using type = E;
+};
+template <class E>
+struct StepEnv<E, true, std::void_t<typename E::Rollout>> {
+  using type = typename E::Rollout;
+};
+
 // minimum resident waves per SIMD the fused kernels are compiled for (caps their registers): E::kMinWaves, else 1
 #ifndef GX_FUSED_MIN_WAVES
 #define GX_FUSED_MIN_WAVES 1
@@ -243,6 +254,7 @@ struct MinWavesRollout<E, std::void_t<decltype(E::kMinWavesRollout)>> {
 // SINGLE: exactly one step per launch (a.k_steps is 1), known at compile time; the form that requests a trip ahead.
 template <class E, int MODE, int POLICY, bool FUSED, bool BOUNDED, bool CACHED = false, bool ROWS = false, bool SINGLE = false>
 __global__ void __launch_bounds__(kClassicBlock, (FUSED && BOUNDED) ? (CACHED ? MinWavesRollout<E>::value : MinWaves<E>::value) : 1) classic_step_kernel(StepArgs a) {
+  using ES = typename StepEnv<E, CACHED>::type;  // whose step() and reset() this kernel runs
   using Real = typename E::Real;
   using Act = typename E::Act;
   using Rew = typename E::Rew;
@@ -251,11 +263,12 @@ __global__ void __launch_bounds__(kClassicBlock, (FUSED && BOUNDED) ? (CACHED ? 
   constexpr int NR = RegState<E>::value;
   constexpr int W = E::W;
   constexpr int WO = WriteOnlyRows<E>::value;
+  static_assert(ES::NS == NS && RegState<ES>::value == NR, "the rollout form steps the same rows");
   constexpr bool PARK = StateInLds<E>::value && !(CACHED && MinWavesRollout<E>::unpark);
   static_assert(!PARK || (NR == NS && !E::kDerivedObs), "the LDS form holds the stored rows only");
   __shared__ Real parked[PARK ? NS : 1][W][kClassicBlock];
   const int lane = threadIdx.x;
-  if constexpr (UsesSinCosTable<E>::value && MODE == GX_MODE_EXACT) sincos_lds_fill();
+  if constexpr (UsesSinCosTable<ES>::value && MODE == GX_MODE_EXACT) sincos_lds_fill();
 
   const bool autoreset = FUSED ? true : (a.flags & GX_AUTORESET) != 0;
   const bool record = FUSED ? true : (a.flags & GX_RECORD_STATS) != 0;
@@ -399,11 +412,11 @@ __global__ void __launch_bounds__(kClassicBlock, (FUSED && BOUNDED) ? (CACHED ? 
           Real cur[NR] = {};
 #pragma unroll
           for (int c = WO; c < NS; c++) cur[c] = parked[c][j][lane];
-          E::template step<MODE, BOUNDED>(cur, steps[j], act[j], reward[j], d);
+          ES::template step<MODE, BOUNDED>(cur, steps[j], act[j], reward[j], d);
 #pragma unroll
           for (int c = 0; c < NS; c++) parked[c][j][lane] = cur[c];
         } else {
-          E::template step<MODE, BOUNDED>(s[j], steps[j], act[j], reward[j], d);
+          ES::template step<MODE, BOUNDED>(s[j], steps[j], act[j], reward[j], d);
         }
         // Wrappers.TimeLimit.cs:26-31; its counter always equals the env's own
         bool t = time_limit > 0 && steps[j] >= time_limit;
@@ -441,7 +454,7 @@ __global__ void __launch_bounds__(kClassicBlock, (FUSED && BOUNDED) ? (CACHED ? 
           if (pending) {
             const int jj = __ffs((int)pending) - 1;
             Real fresh[NR];
-            E::reset(fresh, key, env0 + (uint64_t)jj);
+            ES::reset(fresh, key, env0 + (uint64_t)jj);
             if constexpr (PARK) {
 #pragma unroll
               for (int c = 0; c < NS; c++) parked[c][jj][lane] = fresh[c];

@@ -18,6 +18,8 @@ print("acrobot fast32", run(["--env", "acrobot", "--mode", "fast32", "--policy",
 print("acrobot rk4 single step", run(["--env", "acrobot", "--rk4", "--policy", "random"]), flush=True)
 print("acrobot rk4 rollout 64", run(["--env", "acrobot", "--rk4", "--rollout", "64", "--steps", "5", "--warmup", "1"]), flush=True)
 print("cartpole rollout 64", run(["--env", "cartpole", "--rollout", "64", "--steps", "5", "--warmup", "1"]), flush=True)
+for e in ("mountaincar", "mountaincarcontinuous", "pendulum", "acrobot"):
+    print(e + " rollout 64", run(["--env", e, "--rollout", "64", "--steps", "5", "--warmup", "1"]), flush=True)
 for env in ("cartpole", "mountaincar", "mountaincarcontinuous", "pendulum", "acrobot"):
     print(env, "fp64 mode", run(["--env", env, "--mode", "fp64"]), flush=True)
 print("taxi stub 64Mi", run(["--env", "taxi", "--num-envs", str(1 << 26)]), flush=True)
