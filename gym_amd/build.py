@@ -33,12 +33,19 @@ def csrc_hash():
     code they were taken on."""
     import hashlib
 
+    import re
+
     h = hashlib.sha256()
     files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip", ".cpp")))
     files.append(os.path.join(os.path.dirname(HERE), "include", "gymx.h"))
     for f in files:
         h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+        # the code only: comments and layout do not change what was measured (none of these sources holds a
+        # comment marker inside a string literal)
+        text = open(f, "r", encoding="utf-8").read()
+        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", " ", text)
+        h.update(" ".join(text.split()).encode())
     return h.hexdigest()[:16]
 
 

@@ -93,9 +93,9 @@ struct CartPole {
   static __device__ __forceinline__ Act sample(uint32_t w) { return word_below(w, NACT); }
 };
 
-// TABLE: EXACT sin and cos through the LDS table (gx_trig.h).  The two routines round to the same float for every
-// float argument of these envs but one in 3.3 * 10^9 each (tests/host_math_check.cpp walks them all), so which
-// one a kernel uses is a matter of speed only: the table routine is a third shorter, and its table costs every
+// TABLE: EXACT sin and cos through the LDS table (gx_trig.h).  Over every float argument of these envs (1.3 * 10^10
+// results, tests/host_math_check.cpp with stride 0) the table routine differs from the C library's float in two
+// results and the polynomial routine in three, so which one a kernel uses is a matter of speed only: the table routine is a third shorter, and its table costs every
 // workgroup a 2 KiB fill.  The K = 64 rollouts gain with it (Pendulum 4.90 -> 4.22 ms at 16 Mi envs), the single
 // steps, which wait on memory, lose 0.5-2 % and keep the polynomial routine.
 template <int MODE, bool TABLE>
