@@ -331,3 +331,33 @@ def test_caller_supplied_table_64mi(oracle):
     st = v["state_int"][0, :n]
     assert int(st.min()) >= 0 and int(st.max()) < 300 and int(v["state_int"][1, :n].max()) <= 40
     g.close()
+
+
+@pytest.mark.parametrize("name,env_id,extra", [("mcc", L.ENV_MOUNTAINCAR_CONT, 0), ("pendulum", L.ENV_PENDULUM, 0),
+                                                ("acrobot", L.ENV_ACROBOT, 0), ("acrobot-rk4", L.ENV_ACROBOT, L.ACROBOT_RK4)],
+                         ids=["mcc", "pendulum", "acrobot", "acrobot-rk4"])
+def test_device_action_steps_equal_in_kernel_policy_steps_16mi(name, env_id, extra):
+    """16 Mi envs: the step that reads its actions from a device row (the form that requests a lane's next trip ahead,
+    at the grid a batch of this size gets) against the step that samples the same actions in the kernel; the whole
+    batch bit for bit, statistics included."""
+    import torch
+    flags = FUSED | extra
+    a = DeviceBatch(ctx(), env_id, N16, seed=8, flags=flags)
+    b = DeviceBatch(ctx(), env_id, N16, seed=8, flags=flags)
+    a.reset(); b.reset()
+    stride = int(a.view().stride)
+    dev = torch.zeros(stride, dtype=torch.float32 if a.info.action_dtype == L.F32 else torch.int32, device="cuda")
+    stream = torch.cuda.Stream()
+    for _ in range(6):
+        a.sample_actions(a.tick, dev.data_ptr(), stream.cuda_stream)
+        a.step_device(dev.data_ptr(), stream.cuda_stream)
+        b.step_random()
+    stream.synchronize(); b.ctx.synchronize()
+    va, vb = torch_views(a), torch_views(b)
+    wide = torch.int64 if va["state_real"].dtype == torch.float64 else torch.int32
+    assert torch.equal(va["state_real"].view(wide), vb["state_real"].view(wide))
+    assert torch.equal(va["state_int"], vb["state_int"])
+    assert torch.equal(va["done"], vb["done"])
+    sa, sb = a.stats(), b.stats()
+    assert (sa.episodes, sa.sum_length) == (sb.episodes, sb.sum_length)
+    a.close(); b.close()
